@@ -1,0 +1,311 @@
+/*
+ * fora_twin.c -- CPU twin of the HIP path's schedule and arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY (see fora_oracle.h).  PARITY UNPINNED against a built
+ * reference (none can be built here); this file restates the SAME algorithm as
+ * fora_oracle.c (citations below) with the two changes the GPU design makes:
+ *
+ *   1. level-synchronous (Jacobi) frontier order instead of the FIFO of
+ *      algo.h:980-1017 -- every node at/over threshold is popped in the same
+ *      level, their increments land together, nodes that CROSS their threshold
+ *      during the level form the next frontier;
+ *   2. residue / reserve / ppr are unsigned 2^-62 fixed point (1.0 == 2^62), so
+ *      every accumulation is an exact integer add: the result does not depend on
+ *      the order in which a GPU's atomics land, total mass is conserved exactly
+ *      (sum reserve + sum residue == 2^62), and the HIP path can be compared
+ *      BIT FOR BIT with this file.
+ *
+ * Both changes keep the push invariant of algo.h:954-1018
+ *   pi(s,.) = reserve + sum_v residue[v] * pi(v,.)
+ * and the exit condition residue[v] < rmax*outdeg(v); tests check both families
+ * against the power iteration of query.h:1192-1224.
+ */
+#include "fora_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+static inline uint64_t mulshift62(uint64_t r, uint64_t a) { return (uint64_t)(((u128)r * a) >> 62); }
+static inline double fix2d(uint64_t x) { return ldexp((double)x, -62); }
+
+/* alpha as 2^-62 fixed point: exact for the double alpha (0.2 -> 922337203685477632). */
+uint64_t orc_twin_alpha_fix(double alpha) { return (uint64_t)ldexp(alpha, 62); }
+
+/* threshold unit T1 = ceil(rmax * 2^62); node threshold = T1 * outdeg (saturating),
+ * the integer form of "residue/outdeg >= rmax" (algo.h:1012). */
+uint64_t orc_twin_rmax_fix(double rmax) {
+    double t = ceil(ldexp(rmax, 62));
+    if (t >= 9223372036854775808.0) return UINT64_MAX >> 1;
+    if (t < 1.0) return 1;
+    return (uint64_t)t;
+}
+
+static inline uint64_t node_thr(uint64_t t1, int64_t deg) {
+    if (deg == 0) return 1; /* residue/0 = +inf >= rmax for any residue > 0 */
+    u128 p = (u128)t1 * (uint64_t)deg;
+    return (p >> 64) ? UINT64_MAX : (uint64_t)p;
+}
+
+void orc_fix_to_double(const uint64_t *in, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = fix2d(in[i]);
+}
+
+/* Runs levels until the frontier is empty.  frontier holds *fn nodes on entry. */
+static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, uint64_t t1,
+                        uint64_t afix, uint64_t *residue, uint64_t *reserve, int32_t *frontier,
+                        int64_t fn, int32_t *next, uint64_t *inc, orc_twin_push_stats *st,
+                        int64_t *level_sizes, int64_t cap) {
+    while (fn > 0) {
+        if (level_sizes && st->levels < cap) level_sizes[st->levels] = fn;
+        st->levels++;
+        uint64_t dang = 0;
+        /* pop phase (algo.h:983-992, 1002): every frontier node gives up its residue */
+        for (int64_t i = 0; i < fn; i++) {
+            int32_t v = frontier[i];
+            uint64_t r = residue[v];
+            residue[v] = 0;
+            uint64_t a = mulshift62(r, afix); /* v_residue * alpha */
+            uint64_t push = r - a;            /* (1-alpha) * v_residue */
+            int64_t deg = row_ptr[v + 1] - row_ptr[v];
+            st->pops++;
+            if (deg == 0) { /* algo.h:993-994: dangling mass goes to the source */
+                reserve[v] += a;
+                dang += push;
+                inc[i] = 0;
+            } else {
+                uint64_t q = push / (uint64_t)deg;
+                reserve[v] += a + (push - q * (uint64_t)deg); /* division remainder stays reserved */
+                inc[i] = q;
+            }
+        }
+        /* expand phase (algo.h:1003-1016) with threshold-crossing detection */
+        int64_t nn = 0;
+        for (int64_t i = 0; i < fn; i++) {
+            int32_t v = frontier[i];
+            uint64_t q = inc[i];
+            for (int64_t e = row_ptr[v]; e < row_ptr[v + 1]; e++) {
+                int32_t w = col[e];
+                uint64_t old = residue[w], nw = old + q;
+                residue[w] = nw;
+                st->relax++;
+                uint64_t thr = node_thr(t1, row_ptr[w + 1] - row_ptr[w]);
+                if (old < thr && nw >= thr) next[nn++] = w;
+            }
+        }
+        if (dang) { /* algo.h:994-998 */
+            uint64_t old = residue[s], nw = old + dang;
+            residue[s] = nw;
+            uint64_t thr = node_thr(t1, row_ptr[s + 1] - row_ptr[s]);
+            if (old < thr && nw >= thr) next[nn++] = s;
+        }
+        memcpy(frontier, next, sizeof(int32_t) * (size_t)nn);
+        fn = nn;
+    }
+}
+
+/* Twin of forward_local_update_linear (algo.h:954-1018). */
+int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
+                  double alpha, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *st,
+                  int64_t *level_sizes, int64_t cap) {
+    orc_twin_push_stats z = {0, 0, 0, 0};
+    memset(residue, 0, sizeof(uint64_t) * (size_t)n);
+    memset(ppr, 0, sizeof(uint64_t) * (size_t)n);
+    if (row_ptr[s + 1] == row_ptr[s]) { /* algo.h:961-965 */
+        ppr[s] = ORC_FIX_ONE;
+        z.rsum_fix = 0;
+        if (st) *st = z;
+        return 0;
+    }
+    int32_t *frontier = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    residue[s] = ORC_FIX_ONE; /* algo.h:976 */
+    frontier[0] = s;          /* the source is pushed unconditionally (algo.h:973,980) */
+    twin_levels(row_ptr, col, s, orc_twin_rmax_fix(rmax), orc_twin_alpha_fix(alpha), residue, ppr,
+                frontier, 1, next, inc, &z, level_sizes, cap);
+    uint64_t reserved = 0;
+    for (int32_t v = 0; v < n; v++) reserved += ppr[v];
+    z.rsum_fix = ORC_FIX_ONE - reserved; /* == sum of residue, exactly */
+    if (st) *st = z;
+    free(frontier); free(next); free(inc);
+    return 0;
+}
+
+/* Twin of query.h:270,282,314 (and :349,:364 for --opt): per node walk counts. */
+uint64_t orc_twin_walk_counts(int32_t n, const uint64_t *residue, uint64_t rsum_fix, double omega,
+                              double alpha, int opt, uint64_t *num_s_rw) {
+    memset(num_s_rw, 0, sizeof(uint64_t) * (size_t)n);
+    if (rsum_fix == 0) return 0;
+    double check_rsum = fix2d(rsum_fix);
+    if (opt) check_rsum *= (1 - alpha);
+    unsigned long long N = (unsigned long long)(omega * check_rsum);
+    uint64_t afix = orc_twin_alpha_fix(alpha);
+    for (int32_t v = 0; v < n; v++) {
+        uint64_t r = residue[v];
+        if (!r) continue;
+        if (opt) r -= mulshift62(r, afix);
+        num_s_rw[v] = (uint64_t)ceil(fix2d(r) / check_rsum * (double)N);
+    }
+    return N;
+}
+
+/* Twin of compute_ppr_with_fwdidx (query.h:255-327) / _opt (query.h:334-413).
+ * ppr holds the reserve on entry and is refined in place.  Walk j of node v adds
+ * r/num (+1 unit for the first r%num walks), so sum(ppr) stays exactly 2^62. */
+int orc_twin_refine(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                    const uint64_t *residue, uint64_t rsum_fix, double omega, double alpha, int opt,
+                    uint64_t seed, const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                    uint64_t *ppr, orc_refine_stats *st) {
+    orc_refine_stats z = {0, 0, 0};
+    int64_t steps = 0;
+    if (rsum_fix != 0) { /* query.h:267-268 */
+        double check_rsum = fix2d(rsum_fix);
+        if (opt) check_rsum *= (1 - alpha);                             /* query.h:349 */
+        unsigned long long N = (unsigned long long)(omega * check_rsum); /* query.h:270 */
+        uint64_t afix = orc_twin_alpha_fix(alpha);
+        for (int32_t v = 0; v < n; v++) {
+            uint64_t r = residue[v];
+            if (!r) continue;
+            if (opt) { /* query.h:363-364 */
+                uint64_t a = mulshift62(r, afix);
+                ppr[v] += a;
+                r -= a;
+            }
+            uint64_t num = (uint64_t)ceil(fix2d(r) / check_rsum * (double)N); /* query.h:282 */
+            if (num == 0) continue; /* reference: NaN weight, zero iterations */
+            uint64_t incr = r / num, rem = r - incr * num;
+            uint64_t from_idx = 0;
+            if (rw_idx) { /* query.h:290-307 */
+                from_idx = num > cnt[v] ? cnt[v] : num;
+                for (uint64_t j = 0; j < from_idx; j++) ppr[rw_idx[off[v] + j]] += incr + (j < rem);
+                z.n_idx_hit += from_idx;
+            }
+            for (uint64_t j = from_idx; j < num; j++) { /* query.h:320-323 */
+                int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, 0, v, j, alpha, opt, &steps);
+                ppr[des] += incr + (j < rem);
+            }
+            z.n_walks += num;
+        }
+    }
+    z.walk_steps = (uint64_t)steps;
+    if (st) *st = z;
+    return 0;
+}
+
+/* Twin of fora_query_basic (query.h:841-907, non --balanced). */
+int orc_twin_query(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
+                   double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                   const uint64_t *off, const uint64_t *cnt, uint64_t *residue, uint64_t *ppr,
+                   orc_twin_push_stats *pst, orc_refine_stats *rst) {
+    orc_twin_push_stats ps;
+    orc_twin_push(n, row_ptr, col, s, rmax, alpha, residue, ppr, &ps, NULL, 0);
+    orc_twin_refine(n, row_ptr, col, s, residue, ps.rsum_fix, omega, alpha, opt, seed, rw_idx, off,
+                    cnt, ppr, rst);
+    if (pst) *pst = ps;
+    return 0;
+}
+
+typedef struct { int32_t id; uint64_t sc; } idfix;
+static int cmp_idfix(const void *a, const void *b) {
+    const idfix *x = (const idfix *)a, *y = (const idfix *)b;
+    if (x->sc != y->sc) return (x->sc < y->sc) - (x->sc > y->sc);
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* Twin of fora_query_topk_new (query.h:972-1045) + topk_ppr (algo.h:592-610).
+ * The incremental push (algo.h:1020-1093) restarts each round from every node whose
+ * residue is at/over the round's threshold (the reference carries the same set in
+ * forward_from whenever the round's rmax >= lowest_delta_rmax). */
+int orc_twin_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                        int32_t k, double epsilon, double alpha, double rmax_scale, uint64_t seed,
+                        const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                        int32_t *ids, double *scores, int32_t *rounds, uint64_t *ppr_out) {
+    if (k == 0) k = 500;
+    const double min_delta = 1.0 / n;
+    const double init_delta = 1.0 / k / 10;
+    const double new_pfail = 1.0 / n / n;
+    double pfail = new_pfail, delta = init_delta;
+    uint64_t afix = orc_twin_alpha_fix(alpha);
+    uint64_t *residue = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *reserve = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *ppr = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *cursor = rw_idx ? (uint64_t *)calloc((size_t)n, sizeof(uint64_t)) : NULL;
+    int32_t *frontier = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    int32_t nround = 0;
+    residue[s] = ORC_FIX_ONE;
+
+    while (delta >= min_delta) {
+        double rmax, omega;
+        orc_fora_topk_setting(m, epsilon, delta, pfail, rmax_scale, &rmax, &omega);
+        nround++;
+        if (row_ptr[s + 1] == row_ptr[s]) { /* query.h:1007-1011 */
+            residue[s] = 0;
+            reserve[s] = ORC_FIX_ONE;
+            memcpy(ppr, reserve, sizeof(uint64_t) * (size_t)n);
+            break;
+        }
+        uint64_t t1 = orc_twin_rmax_fix(rmax);
+        int64_t fn = 0;
+        for (int32_t v = 0; v < n; v++)
+            if (residue[v] >= node_thr(t1, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
+        orc_twin_push_stats ps = {0, 0, 0, 0};
+        twin_levels(row_ptr, col, s, t1, afix, residue, reserve, frontier, fn, next, inc, &ps, NULL, 0);
+        uint64_t reserved = 0;
+        for (int32_t v = 0; v < n; v++) reserved += reserve[v];
+        uint64_t rsum_fix = ORC_FIX_ONE - reserved;
+        memcpy(ppr, reserve, sizeof(uint64_t) * (size_t)n); /* query.h:243-253 */
+        if (rsum_fix != 0) {
+            for (int32_t v = 0; v < n; v++) {
+                uint64_t r = residue[v];
+                if (!r) continue;
+                if (rw_idx) { /* query.h:558-611 */
+                    uint64_t a = mulshift62(r, afix);
+                    ppr[v] += a;
+                    r -= a;
+                    uint64_t num = (uint64_t)ceil(fix2d(r) * omega);
+                    if (!num) continue;
+                    uint64_t incr = r / num, rem = r - incr * num;
+                    uint64_t used = cursor[v], remaining = cnt[v] - used;
+                    uint64_t from_idx = num <= remaining ? num : remaining;
+                    for (uint64_t j = 0; j < from_idx; j++) ppr[rw_idx[off[v] + used + j]] += incr + (j < rem);
+                    cursor[v] = used + from_idx;
+                    for (uint64_t j = from_idx; j < num; j++) {
+                        int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, (uint32_t)nround, v, j, alpha, 1, NULL);
+                        ppr[des] += incr + (j < rem);
+                    }
+                } else { /* query.h:615-632 */
+                    uint64_t num = (uint64_t)ceil(fix2d(r) * omega);
+                    if (!num) continue;
+                    uint64_t incr = r / num, rem = r - incr * num;
+                    for (uint64_t j = 0; j < num; j++) {
+                        int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, (uint32_t)nround, v, j, alpha, 0, NULL);
+                        ppr[des] += incr + (j < rem);
+                    }
+                }
+            }
+        }
+        /* algo.h:578-590 + query.h:1030: kth >= (1+eps)*delta  <=>  at least k entries >= it */
+        double T = (1 + epsilon) * delta;
+        int64_t above = 0;
+        for (int32_t v = 0; v < n; v++) above += fix2d(ppr[v]) >= T;
+        if (above >= k || delta <= min_delta) break;
+        delta = delta / 4.0 > min_delta ? delta / 4.0 : min_delta;
+    }
+    idfix *all = (idfix *)malloc(sizeof(idfix) * ((size_t)n + 1));
+    int64_t na = 0;
+    for (int32_t v = 0; v < n; v++)
+        if (ppr[v]) { all[na].id = v; all[na].sc = ppr[v]; na++; }
+    qsort(all, (size_t)na, sizeof(idfix), cmp_idfix);
+    for (int32_t i = 0; i < k; i++) {
+        if (i < na) { ids[i] = all[i].id; scores[i] = fix2d(all[i].sc); }
+        else { ids[i] = 0; scores[i] = 0.0; }
+    }
+    if (rounds) *rounds = nround;
+    if (ppr_out) memcpy(ppr_out, ppr, sizeof(uint64_t) * (size_t)n);
+    free(all); free(residue); free(reserve); free(ppr); free(cursor); free(frontier); free(next); free(inc);
+    return 0;
+}
