@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- SSPPR queries/sec of the HIP FORA path (BASELINE.json metric).
+
+One "step" = one pass of the hot path (forward push + random-walk refinement) over a
+batch of --queries synthetic source queries on this rank's GPU.  Default workload is
+BASELINE.json configs[1]: webstanford-sized graph, eps=0.5, query_size=1000, online
+walks (no index), 1 x MI355X.  N>1: one process per GPU (torch.distributed.run), the
+global query list is sharded i mod N, no data-path collective (weak scaling: every
+rank runs --queries queries per step).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--graph", default="webstanford", help="synth preset (webstanford|livejournal|small|tiny)")
+    ap.add_argument("--dangling", default="none", choices=["none", "rmat"])
+    ap.add_argument("--queries", type=int, default=1000, help="query_size per rank per step")
+    ap.add_argument("--epsilon", type=float, default=0.5)
+    ap.add_argument("--with-idx", action="store_true")
+    ap.add_argument("--opt", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="queries in flight per launch (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(g, sources, rmax, omega, args, index):
+    """The oracle (FIFO push + walks in the reference's arithmetic, oracle/fora_oracle.c)
+    timed on one host core over a bounded sample of the same query list."""
+    import oracle_lib as O
+    t0 = time.perf_counter()
+    done, pops, relax, walks = 0, 0, 0, 0
+    for s in sources:
+        _, st = O.query(g, int(s), rmax, omega, opt=args.opt, seed=0x464F5241, index=index)
+        done += 1
+        pops += st["pops"]; relax += st["relax"]; walks += st["n_walks"]
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    # a few more sources push-only, to steady the algorithmic P/E estimate
+    t1 = time.perf_counter()
+    ppops, prelax, pn = pops, relax, done
+    for s in sources[done:done + 96]:
+        p = O.push_fifo(g, int(s), rmax)
+        ppops += p["pops"]; prelax += p["relax"]; pn += 1
+        if time.perf_counter() - t1 > 0.5 * args.cpu_seconds:
+            break
+    return {
+        "value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+        "sample": f"first {done} of the {len(sources)} bench sources, oracle FIFO push + "
+                  f"{'indexed' if index is not None else 'online Philox'} walks, 1 thread, {dt:.1f} s",
+        "walks_per_query": walks / max(1, done),
+    }, ppops / max(1, pn), prelax / max(1, pn)
+
+
+def main():
+    args = parse()
+    import torch  # first: the process must use ONE HIP runtime (torch's), the library binds to it
+    import torch.distributed as dist
+    import numpy as np
+    import fora_amd
+    from fora_amd import synth
+    from fora_amd.dist import env_world, shard_sources, max_over_ranks, sum_over_ranks
+
+    rank, local_rank, world = env_world()
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
+    eng = fora_amd.Engine(local_rank)
+    arch, cus, hbm = eng.device_info()
+    eng.set_graph(n, m, row_ptr, col)
+    eng.set_params(alpha=0.2, epsilon=args.epsilon, opt=args.opt, seed=0x464F5241)
+    rmax, omega = eng.get_params()
+    if args.batch:
+        eng.set_batch(args.batch)
+    t_idx = 0.0
+    if args.with_idx:
+        t0 = time.perf_counter()
+        eng.build_index()
+        t_idx = time.perf_counter() - t0
+
+    # global query list, sharded i mod world; every rank gets --queries sources per step
+    all_sources = synth.query_set(n, args.queries * world, 20261001)
+    mine = shard_sources(all_sources, rank, world)
+
+    def step():
+        _, st = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.reset_timing()
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, world, dev)
+    tm = eng.timing()
+
+    # sanity inside the bench: every query conserved mass exactly, none was skipped
+    assert len(last) == len(mine)
+    assert all(s["ppr_sum_fix"] == 1 << 62 for s in last), "mass not conserved"
+    nd = sum(1 for s in last if not s["dangling_source"])
+    tot = sum_over_ranks([len(mine), nd, tm["walks"], tm["walk_steps"], tm["relax"], tm["pops"]], world, dev)
+
+    if rank == 0:
+        qps = tot[0] * args.steps / dt
+        out = {
+            "metric": "SSPPR queries/sec at eps=0.5", "value": qps, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 fixed-point 2^-62 (f64 at the boundary)", "data": "synthetic",
+            "config": {
+                "workload": f"{args.graph}-sized R-MAT (n={n}, m={m}, dangling={args.dangling}) eps={args.epsilon} "
+                            f"query_size={args.queries}/GPU, fora push + "
+                            f"{'indexed' if args.with_idx else 'online Philox'} walks"
+                            f"{' --opt' if args.opt else ''} on {world}x MI355X",
+                "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "query_size_per_gpu": args.queries,
+                "with_idx": bool(args.with_idx), "opt": bool(args.opt), "batch": eng.get_batch(),
+                "sharding": f"sources i mod {world}", "non_dangling_sources": int(tot[1]),
+                "rmax": rmax, "omega": omega, "device": arch, "cus": cus,
+            },
+        }
+        q_timed = len(mine) * args.steps  # queries this rank ran in the timed region
+        cpu, p_fifo, e_fifo = (None, None, None)
+        if not args.no_cpu:
+            import oracle_lib as O
+            g = O.Graph(n, m, row_ptr, col)
+            index = None
+            if args.with_idx:
+                rw, off, cnt = eng.get_index()
+                index = (rw, off, cnt)
+            cpu, p_fifo, e_fifo = cpu_baseline(g, mine, rmax, omega, args, index)
+            out["cpu_baseline"] = cpu
+        # roofline of the dominant push kernel (k_push_expand): ALGORITHMIC bytes = 24 B per edge
+        # relaxation of the sequential FIFO oracle; relaxations the level-synchronous
+        # schedule adds on top are not credited.  Duration: HIP events around every launch.
+        if tm["push_expand_launches"]:
+            e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
+            p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
+            alg_bytes = 24.0 * e_unit * q_timed
+            launches = tm["push_expand_launches"]
+            avg_ms = tm["push_expand_ms"] / launches
+            achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "fora::k_push_expand", "launches": int(launches), "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "fifo_relaxations_per_query": e_unit, "fifo_pops_per_query": p_unit,
+                "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed),
+                "push_total": {  # both push kernels against 52*P + 24*E
+                    "achieved": (52.0 * p_unit + 24.0 * e_unit) * q_timed
+                                / ((tm["push_expand_ms"] + tm["push_pop_ms"]) * 1e-3) / 1e9,
+                    "ms": tm["push_expand_ms"] + tm["push_pop_ms"]},
+            }
+        walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
+        out["phases"] = {
+            "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"],
+            "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "other_ms": tm["other_ms"],
+            "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
+            "walks": tm["walks"], "walk_steps": tm["walk_steps"],
+            "walks_per_s": tm["walks"] / max(1e-9, tm["walk_ms"] * 1e-3),
+            "walk_algorithmic_GBps": walk_bytes / max(1e-9, tm["walk_ms"] * 1e-3) / 1e9,
+            "index_build_s": t_idx,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

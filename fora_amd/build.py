@@ -1,0 +1,72 @@
+"""Builds every native artefact in-tree (no JIT cache): the gfx950 HIP library
+fora_amd/libfora_hip.so, the host CLI fora_amd/bin/fora, and (checker only) the
+CPU oracle oracle/libfora_oracle.so.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fora_amd")
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libfora_hip.so")
+CLI = os.path.join(PKG, "bin", "fora")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources(*dirs):
+    out = []
+    for d in dirs:
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h", ".cpp", ".c", ".hpp")) or f == "Makefile":
+                out.append(os.path.join(d, f))
+    return out
+
+
+def build_hip(force=False):
+    srcs = _sources(CSRC, os.path.join(ROOT, "include"))
+    if not force and _newer(LIB, srcs):
+        return LIB
+    cmd = [HIPCC, *HIP_FLAGS, "-shared", "-o", LIB, os.path.join(CSRC, "fora_hip.hip")]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_cli(force=False):
+    host = os.path.join(CSRC, "host")
+    if not os.path.isdir(host):
+        return None
+    srcs = _sources(host, os.path.join(ROOT, "include")) + [LIB]
+    if not force and _newer(CLI, srcs):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cpps = [s for s in _sources(host) if s.endswith(".cpp")]
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", CLI, *cpps,
+           "-L", PKG, "-lfora_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    subprocess.run(cmd, check=True)
+    return CLI
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return os.path.join(ROOT, "oracle", "libfora_oracle.so")
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_cli(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force=True)
+    print("built", LIB)

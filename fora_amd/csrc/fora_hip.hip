@@ -1,0 +1,673 @@
+// fora_hip.hip -- C ABI (include/fora_hip.h) over the gfx950 kernels of fora_kernels.h.
+//
+// Owns all device state of one GPU: the CSR graph, the optional walk index, and a
+// workspace of `batch` query slots.  The host side only sequences kernel launches;
+// there is no CPU fallback: without a HIP device every entry point fails.
+#include "fora_kernels.h"
+#include "../../include/fora_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fora;
+
+namespace {
+
+struct EvPair {
+    hipEvent_t a, b;
+    int kind; // 0 pop, 1 expand, 2 walk_alloc, 3 walk, 4 other, 5 batch
+};
+
+} // namespace
+
+struct fora_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop{};
+
+    // graph
+    int32_t n = 0;
+    int64_t m_attr = 0, nnz = 0;
+    std::vector<int64_t> h_row_ptr;
+    int64_t *d_row_ptr = nullptr;
+    int32_t *d_col = nullptr;
+    uint64_t *d_rowinfo = nullptr;
+    uint32_t *d_deg = nullptr;
+
+    // params
+    bool have_params = false;
+    double alpha = 0.2, epsilon = 0.5, rmax_scale = 1.0, rmax = 0, omega = 0;
+    int opt = 0;
+    uint64_t seed = 0;
+
+    // index
+    int32_t *d_rw_idx = nullptr;
+    uint64_t *d_idx_off = nullptr, *d_idx_cnt = nullptr;
+    uint64_t idx_len = 0;
+    bool have_index = false;
+
+    // workspace
+    int batch_req = 0, B = 0;
+    uint64_t *d_residue = nullptr, *d_ppr = nullptr, *d_wl[2] = {nullptr, nullptr};
+    void *d_scratch = nullptr; // PushSeg list during the push, WalkItem list during the walks
+    uint64_t wl_cap = 0, seg_cap = 0, wit_cap = 0;
+    unsigned long long *d_counters = nullptr; // wl_count | seg_count | wit_count | tot_steps
+    QState *d_qs = nullptr;
+    int32_t *d_src = nullptr;
+    uint32_t *d_err = nullptr;
+    unsigned long long *h_pinned = nullptr; // [MAX_LEVELS + 2] frontier sizes read back
+    std::vector<QState> h_qs;
+
+    // timing
+    bool profiling = true;
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    fora_timing timing{};
+    int grid_blocks = 2048;
+};
+
+namespace {
+
+int fail(fora_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, e_ == hipErrorOutOfMemory ? FORA_E_NOMEM : FORA_E_HIP,               \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+template <typename T> void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_graph(fora_ctx *c) {
+    dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg);
+    c->n = 0; c->nnz = 0;
+}
+void free_index(fora_ctx *c) {
+    dfree(c->d_rw_idx); dfree(c->d_idx_off); dfree(c->d_idx_cnt);
+    c->idx_len = 0; c->have_index = false;
+}
+void free_workspace(fora_ctx *c) {
+    dfree(c->d_residue); dfree(c->d_ppr); dfree(c->d_wl[0]); dfree(c->d_wl[1]); dfree(c->d_scratch);
+    dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr;
+    c->B = 0;
+}
+
+constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
+
+// bytes of workspace one slot needs
+uint64_t slot_bytes(const fora_ctx *c, double omega_hint) {
+    const uint64_t n = (uint64_t)c->n;
+    const uint64_t segs = n + (uint64_t)c->nnz / PUSH_SEG + 64;
+    double walks = omega_hint > 0 ? omega_hint : 0;
+    if (walks > 4e12) walks = 4e12;
+    const uint64_t wits = n + (uint64_t)(walks / WALK_SEG) + 64;
+    const uint64_t scratch = std::max(segs * sizeof(PushSeg), wits * sizeof(WalkItem));
+    return n * 8 * 4 + scratch;
+}
+
+int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    int B = c->batch_req > 0 ? c->batch_req : 0;
+    const uint64_t per = slot_bytes(c, omega_hint);
+    if (B == 0) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(c, hipMemGetInfo(&fr, &tot));
+        uint64_t budget = (uint64_t)(fr * 0.6);
+        B = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, budget / per));
+    }
+    B = std::max(1, B);
+    if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
+    const uint64_t n = (uint64_t)c->n;
+    const uint64_t segs = (uint64_t)B * (n + (uint64_t)c->nnz / PUSH_SEG + 64);
+    double walks = omega_hint > 0 ? omega_hint : 0;
+    if (walks > 4e12) walks = 4e12;
+    const uint64_t wits = (uint64_t)B * (n + (uint64_t)(walks / WALK_SEG) + 64);
+    if (c->B >= B && c->seg_cap >= segs && c->wit_cap >= wits) return FORA_OK;
+    free_workspace(c);
+    const uint64_t slab = (uint64_t)B * n;
+    HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
+    HIPCHK(c, hipMalloc(&c->d_ppr, slab * 8));
+    HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
+    HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
+    const uint64_t scratch = std::max(segs * sizeof(PushSeg), wits * sizeof(WalkItem));
+    HIPCHK(c, hipMalloc(&c->d_scratch, scratch));
+    HIPCHK(c, hipMalloc(&c->d_counters, N_COUNTERS * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_qs, (size_t)B * sizeof(QState)));
+    HIPCHK(c, hipMalloc(&c->d_src, (size_t)B * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->d_err, sizeof(uint32_t)));
+    HIPCHK(c, hipHostMalloc(&c->h_pinned, (MAX_LEVELS + 2) * sizeof(unsigned long long)));
+    c->B = B;
+    c->wl_cap = slab;
+    c->seg_cap = scratch / sizeof(PushSeg);
+    c->wit_cap = scratch / sizeof(WalkItem);
+    c->h_qs.resize(B);
+    return FORA_OK;
+}
+
+Dev make_dev(fora_ctx *c, int nq, bool with_idx) {
+    Dev d{};
+    d.n = c->n; d.nq = nq;
+    d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col; d.deg = c->d_deg;
+    d.residue = c->d_residue; d.ppr = c->d_ppr;
+    d.wl[0] = c->d_wl[0]; d.wl[1] = c->d_wl[1]; d.wl_cap = c->wl_cap;
+    d.seg = (PushSeg *)c->d_scratch; d.seg_cap = c->seg_cap;
+    d.wit = (WalkItem *)c->d_scratch; d.wit_cap = c->wit_cap;
+    d.wl_count = c->d_counters;
+    d.seg_count = c->d_counters + (MAX_LEVELS + 2);
+    d.wit_count = c->d_counters + 2 * (size_t)(MAX_LEVELS + 2);
+    d.tot_steps = d.wit_count + 1;
+    d.qs = c->d_qs; d.src = c->d_src; d.err = c->d_err;
+    d.afix = (uint64_t)std::ldexp(c->alpha, 62);
+    double t = std::ceil(std::ldexp(c->rmax, 62));
+    d.t1 = t >= 9223372036854775808.0 ? (~0ull >> 1) : (t < 1.0 ? 1 : (uint64_t)t);
+    d.alpha32 = (uint32_t)(c->alpha * 4294967296.0);
+    d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
+    d.alpha = c->alpha; d.omega = c->omega; d.opt = c->opt;
+    if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
+    return d;
+}
+
+// ---- event-pair timing of individual launches on the ctx stream
+int ev_begin(fora_ctx *c, int kind) {
+    if (!c->profiling) return -1;
+    if (c->ev_used == c->ev_pool.size()) {
+        EvPair p{};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+        c->ev_pool.push_back(p);
+    }
+    EvPair &p = c->ev_pool[c->ev_used];
+    p.kind = kind;
+    (void)hipEventRecord(p.a, c->stream);
+    return (int)c->ev_used++;
+}
+void ev_end(fora_ctx *c, int h) {
+    if (h >= 0) (void)hipEventRecord(c->ev_pool[h].b, c->stream);
+}
+void ev_collect(fora_ctx *c) { // call after the stream is idle
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) != hipSuccess) continue;
+        switch (c->ev_pool[i].kind) {
+        case 0: c->timing.push_pop_ms += ms; c->timing.push_pop_launches++; break;
+        case 1: c->timing.push_expand_ms += ms; c->timing.push_expand_launches++; break;
+        case 2: c->timing.walk_alloc_ms += ms; break;
+        case 3: c->timing.walk_ms += ms; c->timing.walk_launches++; break;
+        case 4: c->timing.other_ms += ms; break;
+        case 5: c->timing.batch_ms += ms; c->timing.batches++; break;
+        }
+    }
+    c->ev_used = 0;
+}
+
+int check_dev_err(fora_ctx *c) {
+    uint32_t e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x)", e);
+        return fail(c, FORA_E_OVERFLOW, buf);
+    }
+    return FORA_OK;
+}
+
+// Level loop of the push for the slots already initialised (frontier of level 0 in wl[0],
+// its size in wl_count[0]).  Launches run ahead of the host by SPEC levels: an empty
+// level costs two near-empty launches, a host round trip per level would cost more.
+int run_push_levels(fora_ctx *c, const Dev &d) {
+    constexpr int SPEC = 3;
+    hipEvent_t done[SPEC + 1];
+    for (auto &e : done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int rc = FORA_OK;
+    int L = 0;
+    for (;; L++) {
+        if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
+        int h = ev_begin(c, 0);
+        hipLaunchKernelGGL(k_push_pop, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
+        ev_end(c, h);
+        h = ev_begin(c, 1);
+        hipLaunchKernelGGL(k_push_expand, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
+        ev_end(c, h);
+        c->timing.levels++;
+        (void)hipMemcpyAsync(&c->h_pinned[L + 1], &d.wl_count[L + 1], sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, c->stream);
+        (void)hipEventRecord(done[L % (SPEC + 1)], c->stream);
+        if (L >= SPEC) {
+            const int K = L - SPEC;
+            if (hipEventSynchronize(done[K % (SPEC + 1)]) != hipSuccess) { rc = fail(c, FORA_E_HIP, "event sync"); break; }
+            if (c->h_pinned[K + 1] == 0) break;
+        }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (auto &ev : done) (void)hipEventDestroy(ev);
+    if (rc == FORA_OK && e != hipSuccess) rc = fail(c, FORA_E_HIP, std::string("push: ") + hipGetErrorString(e));
+    if (rc == FORA_OK) {
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(c, FORA_E_HIP, std::string("push launch: ") + hipGetErrorString(e));
+    }
+    return rc;
+}
+
+int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
+    const uint64_t bytes = (uint64_t)nq * c->n * 8;
+    int h = ev_begin(c, 4);
+    HIPCHK(c, hipMemsetAsync(c->d_residue, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ppr, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_src, sources, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    ev_end(c, h);
+    return FORA_OK;
+}
+
+enum { RUN_PUSH_ONLY = 1 };
+
+// one batch of <= B sources: push (+ refinement).  Results stay in the slabs.
+int run_query_batch(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int flags) {
+    for (int i = 0; i < nq; i++)
+        if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
+    const int hb = ev_begin(c, 5);
+    int rc = reset_batch_state(c, nq, sources);
+    if (rc) return rc;
+    Dev d = make_dev(c, nq, with_idx);
+    int h = ev_begin(c, 4);
+    hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 0);
+    ev_end(c, h);
+    rc = run_push_levels(c, d);
+    if (rc) return rc;
+    if (!(flags & RUN_PUSH_ONLY)) {
+        const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+        h = ev_begin(c, 2);
+        hipLaunchKernelGGL(k_walk_alloc, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0);
+        ev_end(c, h);
+        h = ev_begin(c, 3);
+        hipLaunchKernelGGL(k_walk<WALK_TO_PPR>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, 0u,
+                           c->opt ? 1 : 0, (int32_t *)nullptr);
+        ev_end(c, h);
+    }
+    {
+        const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 64);
+        h = ev_begin(c, 4);
+        hipLaunchKernelGGL(k_ppr_sum, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d);
+        ev_end(c, h);
+    }
+    unsigned long long steps = 0;
+    HIPCHK(c, hipMemcpyAsync(c->h_qs.data(), c->d_qs, (size_t)nq * sizeof(QState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&steps, d.tot_steps, sizeof(steps), hipMemcpyDeviceToHost, c->stream));
+    ev_end(c, hb);
+    rc = check_dev_err(c);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("batch: ") + hipGetErrorString(e));
+    ev_collect(c);
+    c->timing.walk_steps += steps;
+    for (int i = 0; i < nq; i++) {
+        c->timing.pops += c->h_qs[i].pops;
+        c->timing.relax += c->h_qs[i].relax;
+        c->timing.walks += c->h_qs[i].n_walks;
+    }
+    return FORA_OK;
+}
+
+void fill_stats(const fora_ctx *c, int nq, fora_query_stats *out) {
+    for (int i = 0; i < nq; i++) {
+        const QState &s = c->h_qs[i];
+        fora_query_stats &o = out[i];
+        o.rsum_fix = FIX_ONE - s.reserved;
+        o.rsum = std::ldexp((double)o.rsum_fix, -62);
+        o.n_rw = s.n_rw; o.n_walks = s.n_walks; o.n_idx_hit = s.n_hit;
+        o.pops = s.pops; o.relax = s.relax; o.ppr_sum_fix = s.ppr_sum;
+        o.levels = (int32_t)s.levels; o.dangling_source = (int32_t)s.dangling_source;
+    }
+}
+
+int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int flags, double *ppr_d,
+                 uint64_t *ppr_fix, uint64_t *residue_fix, fora_query_stats *stats) {
+    if (!c) return FORA_E_ARG;
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first");
+    if (nq < 0 || (nq && !sources)) return fail(c, FORA_E_ARG, "bad sources");
+    if (with_idx && !c->have_index) return fail(c, FORA_E_ARG, "with_idx without an index (build or set one)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_workspace(c, nq, c->omega);
+    if (rc) return rc;
+    const uint64_t n = (uint64_t)c->n;
+    for (int b0 = 0; b0 < nq; b0 += c->B) {
+        const int nb = std::min(c->B, nq - b0);
+        rc = run_query_batch(c, sources + b0, nb, with_idx != 0, flags);
+        if (rc) return rc;
+        if (stats) fill_stats(c, nb, stats + b0);
+        const uint64_t bytes = (uint64_t)nb * n * 8;
+        if (ppr_d) {
+            // u64 and f64 have the same size: copy raw, convert in place on the host
+            double *dst = ppr_d + (uint64_t)b0 * n;
+            HIPCHK(c, hipMemcpy(dst, c->d_ppr, bytes, hipMemcpyDeviceToHost));
+            uint64_t *raw = (uint64_t *)dst;
+            for (uint64_t i = 0; i < (uint64_t)nb * n; i++) {
+                uint64_t u = raw[i];
+                dst[i] = std::ldexp((double)u, -62);
+            }
+        }
+        if (ppr_fix) HIPCHK(c, hipMemcpy(ppr_fix + (uint64_t)b0 * n, c->d_ppr, bytes, hipMemcpyDeviceToHost));
+        if (residue_fix) HIPCHK(c, hipMemcpy(residue_fix + (uint64_t)b0 * n, c->d_residue, bytes, hipMemcpyDeviceToHost));
+    }
+    return FORA_OK;
+}
+
+} // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int fora_hip_create(int device, fora_ctx **out) {
+    if (!out) return FORA_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return FORA_E_NOGPU;
+    if (device < 0 || device >= ndev) return FORA_E_ARG;
+    fora_ctx *c = new (std::nothrow) fora_ctx();
+    if (!c) return FORA_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return FORA_E_HIP;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        // kernels are compiled for gfx950 only
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return FORA_E_NOGPU;
+    }
+    const char *p = getenv("FORA_HIP_PROFILE");
+    if (p && p[0] == '0') c->profiling = false;
+    const char *g = getenv("FORA_HIP_GRID");
+    if (g && atoi(g) > 0) c->grid_blocks = atoi(g);
+    *out = c;
+    return FORA_OK;
+}
+
+void fora_hip_destroy(fora_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_workspace(c);
+    free_index(c);
+    free_graph(c);
+    for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *fora_hip_last_error(fora_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int fora_hip_device_info(fora_ctx *c, char *arch, int arch_len, int *cus, uint64_t *hbm_bytes) {
+    if (!c) return FORA_E_ARG;
+    if (arch && arch_len > 0) { strncpy(arch, c->prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)c->prop.totalGlobalMem;
+    return FORA_OK;
+}
+
+int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *row_ptr, const int32_t *col) {
+    if (!c) return FORA_E_ARG;
+    if (n <= 0 || !row_ptr || row_ptr[0] != 0) return fail(c, FORA_E_ARG, "bad graph");
+    const int64_t nnz = row_ptr[n];
+    if (nnz < 0 || (nnz && !col) || nnz >= (1ll << 40)) return fail(c, FORA_E_ARG, "bad graph (nnz)");
+    for (int32_t v = 0; v < n; v++)
+        if (row_ptr[v + 1] < row_ptr[v]) return fail(c, FORA_E_ARG, "row_ptr not monotone");
+    for (int64_t e = 0; e < nnz; e++)
+        if (col[e] < 0 || col[e] >= n) return fail(c, FORA_E_ARG, "edge target out of range"); // graph.h:155-156
+    HIPCHK(c, hipSetDevice(c->device));
+    free_workspace(c);
+    free_index(c);
+    free_graph(c);
+    std::vector<uint64_t> rowinfo((size_t)n);
+    std::vector<uint32_t> deg((size_t)n);
+    for (int32_t v = 0; v < n; v++) {
+        const uint64_t dg = (uint64_t)(row_ptr[v + 1] - row_ptr[v]);
+        if (dg > 0xFFFFFFFFull) return fail(c, FORA_E_ARG, "out-degree over 2^32");
+        deg[v] = (uint32_t)dg;
+        rowinfo[v] = ((uint64_t)row_ptr[v] << 24) | std::min<uint64_t>(dg, DEG_SAT);
+    }
+    HIPCHK(c, hipMalloc(&c->d_row_ptr, ((size_t)n + 1) * 8));
+    HIPCHK(c, hipMalloc(&c->d_col, std::max<size_t>(1, (size_t)nnz) * 4));
+    HIPCHK(c, hipMalloc(&c->d_rowinfo, (size_t)n * 8));
+    HIPCHK(c, hipMalloc(&c->d_deg, (size_t)n * 4));
+    HIPCHK(c, hipMemcpy(c->d_row_ptr, row_ptr, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(c, hipMemcpy(c->d_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_rowinfo, rowinfo.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_deg, deg.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
+    c->n = n; c->m_attr = m_attr; c->nnz = nnz;
+    return FORA_OK;
+}
+
+int fora_hip_set_params(fora_ctx *c, double alpha, double epsilon, double rmax_scale, int opt, uint64_t seed) {
+    if (!c) return FORA_E_ARG;
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!(alpha > 0 && alpha < 1) || !(epsilon > 0) || !(rmax_scale >= 0)) return fail(c, FORA_E_ARG, "bad params");
+    // graph.h:177-178 then algo.h:455-463, in the reference's operand order
+    const double delta = 1.0 / c->n, pfail = 1.0 / c->n;
+    const long long m = c->m_attr;
+    double rmax = epsilon * sqrt(delta / 3 / m / log(2 / pfail));
+    if (opt) rmax *= rmax_scale / (1 - alpha);
+    else rmax *= rmax_scale;
+    const double omega = (2 + epsilon) * log(2 / pfail) / delta / epsilon / epsilon;
+    c->alpha = alpha; c->epsilon = epsilon; c->rmax_scale = rmax_scale; c->opt = opt ? 1 : 0; c->seed = seed;
+    c->rmax = rmax; c->omega = omega; c->have_params = true;
+    return FORA_OK;
+}
+
+int fora_hip_set_params_raw(fora_ctx *c, double alpha, double rmax, double omega, int opt, uint64_t seed) {
+    if (!c) return FORA_E_ARG;
+    if (!(alpha > 0 && alpha < 1) || !(rmax > 0) || !(omega >= 0)) return fail(c, FORA_E_ARG, "bad params");
+    c->alpha = alpha; c->rmax = rmax; c->omega = omega; c->opt = opt ? 1 : 0; c->seed = seed;
+    c->have_params = true;
+    return FORA_OK;
+}
+
+int fora_hip_get_params(fora_ctx *c, double *rmax, double *omega) {
+    if (!c || !c->have_params) return FORA_E_ARG;
+    if (rmax) *rmax = c->rmax;
+    if (omega) *omega = c->omega;
+    return FORA_OK;
+}
+
+int fora_hip_set_batch(fora_ctx *c, int batch) {
+    if (!c || batch < 0) return FORA_E_ARG;
+    if (batch != c->batch_req) { (void)hipSetDevice(c->device); free_workspace(c); }
+    c->batch_req = batch;
+    return FORA_OK;
+}
+int fora_hip_get_batch(fora_ctx *c) { return c ? c->B : FORA_E_ARG; }
+
+// ---- index ---------------------------------------------------------------------
+static uint64_t host_index_sizes(const fora_ctx *c, uint64_t *off, uint64_t *cnt) {
+    // build.h:325-334
+    uint64_t total = 0;
+    for (int32_t v = 0; v < c->n; v++) {
+        const size_t deg = (size_t)(c->h_row_ptr[v + 1] - c->h_row_ptr[v]);
+        unsigned long num_rw;
+        if (c->opt) num_rw = (unsigned long)ceil(deg * c->rmax * (1 - c->alpha) * c->omega);
+        else num_rw = (unsigned long)ceil(deg * c->rmax * c->omega);
+        if (off) off[v] = total;
+        if (cnt) cnt[v] = num_rw;
+        total += num_rw;
+    }
+    return total;
+}
+
+int fora_hip_index_sizes(fora_ctx *c, uint64_t *total, uint64_t *off, uint64_t *cnt) {
+    if (!c || !c->n || !c->have_params) return fail(c, FORA_E_ARG, "set_graph and set_params first");
+    const uint64_t t = host_index_sizes(c, off, cnt);
+    if (total) *total = t;
+    return FORA_OK;
+}
+
+int fora_hip_build_index(fora_ctx *c) {
+    if (!c || !c->n || !c->have_params) return fail(c, FORA_E_ARG, "set_graph and set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> off((size_t)c->n), cnt((size_t)c->n);
+    const uint64_t total = host_index_sizes(c, off.data(), cnt.data());
+    free_index(c);
+    HIPCHK(c, hipMalloc(&c->d_rw_idx, std::max<uint64_t>(1, total) * 4));
+    HIPCHK(c, hipMalloc(&c->d_idx_off, (size_t)c->n * 8));
+    HIPCHK(c, hipMalloc(&c->d_idx_cnt, (size_t)c->n * 8));
+    HIPCHK(c, hipMemcpy(c->d_idx_off, off.data(), (size_t)c->n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_idx_cnt, cnt.data(), (size_t)c->n * 8, hipMemcpyHostToDevice));
+    c->idx_len = total;
+    int rc = ensure_workspace(c, 1, (double)total);
+    if (rc) return rc;
+    Dev d = make_dev(c, 1, true);
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 2048);
+    int h = ev_begin(c, 4);
+    hipLaunchKernelGGL(k_index_alloc, dim3(chunks), dim3(BLOCK), 0, c->stream, d);
+    ev_end(c, h);
+    h = ev_begin(c, 3);
+    hipLaunchKernelGGL(k_walk<WALK_TO_INDEX>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, 0u,
+                       c->opt ? 1 : 0, c->d_rw_idx);
+    ev_end(c, h);
+    rc = check_dev_err(c);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("build_index: ") + hipGetErrorString(e));
+    ev_collect(c);
+    c->have_index = true;
+    return FORA_OK;
+}
+
+int fora_hip_get_index(fora_ctx *c, int32_t *rw_idx, uint64_t len, uint64_t *off, uint64_t *cnt) {
+    if (!c || !c->have_index) return fail(c, FORA_E_ARG, "no index");
+    if (rw_idx && len < c->idx_len) return fail(c, FORA_E_ARG, "rw_idx buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (rw_idx && c->idx_len) HIPCHK(c, hipMemcpy(rw_idx, c->d_rw_idx, c->idx_len * 4, hipMemcpyDeviceToHost));
+    if (off) HIPCHK(c, hipMemcpy(off, c->d_idx_off, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    if (cnt) HIPCHK(c, hipMemcpy(cnt, c->d_idx_cnt, (size_t)c->n * 8, hipMemcpyDeviceToHost));
+    return FORA_OK;
+}
+
+int fora_hip_set_index(fora_ctx *c, const int32_t *rw_idx, uint64_t len, const uint64_t *off, const uint64_t *cnt) {
+    if (!c || !c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!off || !cnt || (len && !rw_idx)) return fail(c, FORA_E_ARG, "bad index");
+    for (int32_t v = 0; v < c->n; v++)
+        if (off[v] + cnt[v] > len) return fail(c, FORA_E_ARG, "index entry range out of bounds");
+    for (uint64_t i = 0; i < len; i++)
+        if (rw_idx[i] < 0 || rw_idx[i] >= c->n) return fail(c, FORA_E_ARG, "index endpoint out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    free_index(c);
+    HIPCHK(c, hipMalloc(&c->d_rw_idx, std::max<uint64_t>(1, len) * 4));
+    HIPCHK(c, hipMalloc(&c->d_idx_off, (size_t)c->n * 8));
+    HIPCHK(c, hipMalloc(&c->d_idx_cnt, (size_t)c->n * 8));
+    if (len) HIPCHK(c, hipMemcpy(c->d_rw_idx, rw_idx, len * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_idx_off, off, (size_t)c->n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_idx_cnt, cnt, (size_t)c->n * 8, hipMemcpyHostToDevice));
+    c->idx_len = len;
+    c->have_index = true;
+    return FORA_OK;
+}
+
+int fora_hip_clear_index(fora_ctx *c) {
+    if (!c) return FORA_E_ARG;
+    (void)hipSetDevice(c->device);
+    free_index(c);
+    return FORA_OK;
+}
+
+// ---- queries -------------------------------------------------------------------
+int fora_hip_query_batch(fora_ctx *c, const int32_t *sources, int nq, int with_idx, double *ppr_out,
+                         fora_query_stats *stats) {
+    return query_common(c, sources, nq, with_idx, 0, ppr_out, nullptr, nullptr, stats);
+}
+
+int fora_hip_query_batch_fix(fora_ctx *c, const int32_t *sources, int nq, int with_idx, uint64_t *ppr_fix_out,
+                             uint64_t *residue_fix_out, fora_query_stats *stats) {
+    return query_common(c, sources, nq, with_idx, 0, nullptr, ppr_fix_out, residue_fix_out, stats);
+}
+
+int fora_hip_push_batch(fora_ctx *c, const int32_t *sources, int nq, uint64_t *reserve_fix_out,
+                        uint64_t *residue_fix_out, fora_query_stats *stats) {
+    return query_common(c, sources, nq, 0, RUN_PUSH_ONLY, nullptr, reserve_fix_out, residue_fix_out, stats);
+}
+
+int fora_hip_walk_counts(fora_ctx *c, const double *residue, double rsum, uint64_t *num_s_rw, uint64_t *n_rw) {
+    if (!c || !c->n || !c->have_params || !residue || !num_s_rw) return fail(c, FORA_E_ARG, "bad call");
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d_r = nullptr;
+    uint64_t *d_num = nullptr, *d_n = nullptr;
+    const size_t n = (size_t)c->n;
+    HIPCHK(c, hipMalloc(&d_r, n * 8));
+    HIPCHK(c, hipMalloc(&d_num, n * 8));
+    HIPCHK(c, hipMalloc(&d_n, 8));
+    HIPCHK(c, hipMemcpy(d_r, residue, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_walk_counts_f64, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+                       c->n, d_r, rsum, c->omega, c->alpha, c->opt, d_num, d_n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(num_s_rw, d_num, n * 8, hipMemcpyDeviceToHost));
+    uint64_t N = 0;
+    HIPCHK(c, hipMemcpy(&N, d_n, 8, hipMemcpyDeviceToHost));
+    if (n_rw) *n_rw = N;
+    dfree(d_r); dfree(d_num); dfree(d_n);
+    return FORA_OK;
+}
+
+int fora_hip_walks(fora_ctx *c, uint32_t stream_id, uint32_t round, int no_zero_hop, const int32_t *starts,
+                   const uint64_t *js, int64_t count, int32_t *dests) {
+    if (!c || !c->n || !c->have_params || count < 0) return fail(c, FORA_E_ARG, "bad call");
+    if (count == 0) return FORA_OK;
+    for (int64_t i = 0; i < count; i++)
+        if (starts[i] < 0 || starts[i] >= c->n) return fail(c, FORA_E_ARG, "walk start out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t *d_s = nullptr, *d_d = nullptr;
+    uint64_t *d_j = nullptr;
+    HIPCHK(c, hipMalloc(&d_s, (size_t)count * 4));
+    HIPCHK(c, hipMalloc(&d_d, (size_t)count * 4));
+    HIPCHK(c, hipMalloc(&d_j, (size_t)count * 8));
+    HIPCHK(c, hipMemcpy(d_s, starts, (size_t)count * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_j, js, (size_t)count * 8, hipMemcpyHostToDevice));
+    Dev d{};
+    d.n = c->n; d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col;
+    d.alpha32 = (uint32_t)(c->alpha * 4294967296.0);
+    d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
+    hipLaunchKernelGGL(k_walks_raw, dim3((unsigned)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, d,
+                       stream_id, round, no_zero_hop, d_s, d_j, count, d_d);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dests, d_d, (size_t)count * 4, hipMemcpyDeviceToHost));
+    dfree(d_s); dfree(d_d); dfree(d_j);
+    return FORA_OK;
+}
+
+int fora_hip_topk_batch(fora_ctx *c, const int32_t *, int, int, double, double, int, int32_t *, double *, int32_t *) {
+    return fail(c, FORA_E_ARG, "topk: not implemented yet");
+}
+
+int fora_hip_reset_timing(fora_ctx *c) {
+    if (!c) return FORA_E_ARG;
+    c->timing = fora_timing{};
+    return FORA_OK;
+}
+int fora_hip_get_timing(fora_ctx *c, fora_timing *out) {
+    if (!c || !out) return FORA_E_ARG;
+    *out = c->timing;
+    return FORA_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,583 @@
+// fora_kernels.h -- device-side data layout and kernels of the FORA SSPPR engine (gfx950).
+//
+// Hot path of wangsibovictor/fora re-designed for MI355X:
+//   forward push   algo.h:954-1018  -> k_push_pop + k_push_expand, one pair per level
+//   walk allocation query.h:270-287 -> k_walk_alloc
+//   random walks   algo.h:124-166, query.h:288-323 -> k_walk<MODE>
+//   index build    build.h:325-354  -> k_index_alloc + k_walk<WALK_TO_INDEX>
+// Many source queries ("slots") run concurrently; slot q owns dense slabs
+// residue[q*n .. (q+1)*n) and ppr[q*n ..) of 2^-62 fixed-point u64 in HBM.
+// All cross-thread accumulation is integer atomics, so results do not depend on
+// the order atomics land in: the whole path is bit-reproducible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fora {
+
+constexpr int BLOCK = 256;          // 4 wave64 per workgroup
+constexpr uint32_t PUSH_SEG = 256;  // max edges per push work item (bounds hub skew)
+constexpr uint32_t WALK_SEG = 1024; // max walks per walk work item
+constexpr uint64_t FIX_ONE = 1ull << 62;
+constexpr uint32_t DEG_SAT = 0xFFFFFFu; // rowinfo low 24 bits: out-degree, saturating
+constexpr int MAX_LEVELS = 1 << 15;
+
+// error flag bits (Dev::err)
+constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4;
+
+struct PushSeg {      // one <=PUSH_SEG-edge slice of a popped node's out-edges
+    int64_t ebeg;     // first edge (index into col)
+    uint64_t inc;     // increment every target gets: ((1-alpha)*r)/outdeg, algo.h:1002
+    uint32_t q;       // slot
+    uint32_t cnt;     // edges in this slice
+};
+
+struct WalkItem {     // <=WALK_SEG walks that start at one residue node
+    uint64_t j0;      // walk number of the first walk (Philox counter word)
+    uint64_t idx_pos; // MODE ppr: rw_idx position of walk j0; MODE index: output position
+    uint64_t incr;    // weight per walk: r / num_s_rw (query.h:283-285)
+    uint64_t rem;     // walks j < rem carry one extra 2^-62 unit (keeps the sum exact)
+    uint32_t q;
+    uint32_t v;       // start node
+    uint32_t cnt;     // walks in this item
+    uint32_t idx_n;   // leading walks of the item served from the index (query.h:290-307)
+};
+
+struct QState {       // per-slot accumulators
+    unsigned long long reserved; // sum of reserve so far; rsum_fix = FIX_ONE - reserved (algo.h:992)
+    unsigned long long dang;     // dangling mass waiting to return to the source (algo.h:994)
+    unsigned long long pops, relax;
+    unsigned long long n_walks, n_hit, n_rw, ppr_sum;
+    uint32_t levels, dangling_source;
+};
+
+struct Dev {
+    int32_t n;
+    int32_t nq; // slots in use this batch
+    const uint64_t *rowinfo; // (first edge << 24) | min(outdeg, DEG_SAT): one 8-B load per node
+    const int64_t *row_ptr;
+    const int32_t *col;
+    const uint32_t *deg;
+    uint64_t *residue, *ppr;
+    uint64_t *wl[2];
+    uint64_t wl_cap;
+    PushSeg *seg;
+    uint64_t seg_cap;
+    WalkItem *wit;
+    uint64_t wit_cap;
+    unsigned long long *wl_count;  // [MAX_LEVELS + 2] frontier size per level
+    unsigned long long *seg_count; // [MAX_LEVELS + 2]
+    unsigned long long *wit_count; // [1]
+    unsigned long long *tot_steps; // [1]
+    QState *qs;
+    const int32_t *src; // source node per slot
+    uint32_t *err;
+    uint64_t afix; // alpha * 2^62
+    uint64_t t1;   // ceil(rmax * 2^62)
+    uint32_t alpha32; // floor(alpha * 2^32): Bernoulli(alpha) stop threshold
+    uint32_t seed_lo, seed_hi;
+    double alpha, omega;
+    int32_t opt;
+    const int32_t *rw_idx;
+    const uint64_t *idx_off, *idx_cnt;
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint64_t mulshift62(uint64_t r, uint64_t a) {
+    return (__umul64hi(r, a) << 2) | ((r * a) >> 62);
+}
+__device__ __forceinline__ double fix2d(uint64_t x) { return (double)x * 0x1p-62; }
+
+// integer form of "residue/outdeg >= rmax" (algo.h:1012); outdeg 0 -> any residue > 0
+__device__ __forceinline__ uint64_t node_thr(uint64_t t1, uint32_t deg) {
+    if (deg == 0) return 1;
+    uint64_t hi = __umul64hi(t1, (uint64_t)deg);
+    return hi ? ~0ull : t1 * (uint64_t)deg;
+}
+
+__device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg, uint64_t &deg) {
+    uint64_t ri = d.rowinfo[v];
+    beg = (int64_t)(ri >> 24);
+    deg = ri & DEG_SAT;
+    if (deg == DEG_SAT) deg = (uint64_t)(d.row_ptr[v + 1] - beg);
+}
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+// exclusive scan over the 256 threads of a block; s_w: 4-entry LDS scratch
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
+    uint32_t wtot;
+    uint32_t x = wave_excl_scan(v, wtot);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[w] = wtot;
+    __syncthreads();
+    uint32_t a0 = s_w[0], a1 = s_w[1], a2 = s_w[2], a3 = s_w[3];
+    total = a0 + a1 + a2 + a3;
+    return x + (w > 0 ? a0 : 0) + (w > 1 ? a1 : 0) + (w > 2 ? a2 : 0);
+}
+
+// wave-aggregated append of `flag`ged 64-bit items to a list (one atomic per wave)
+__device__ __forceinline__ void wave_append(bool flag, uint64_t item, uint64_t *list,
+                                            unsigned long long *count, uint64_t cap, uint32_t *err,
+                                            uint32_t errbit) {
+    const unsigned long long mask = __ballot(flag);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader);
+    if (flag) {
+        uint64_t idx = base + __popcll(mask & ((1ull << lane) - 1));
+        if (idx < cap) list[idx] = item;
+        else atomicOr(err, errbit);
+    }
+}
+
+// Philox4x32-10 (Random123 constants)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// walk allocation in the reference's f64 arithmetic: query.h:282 / :314
+//   num_s_rw = ceil(residual / check_rsum * num_random_walk)
+__device__ __forceinline__ uint64_t walk_count(double residual, double check_rsum, uint64_t N) {
+    return (uint64_t)ceil(residual / check_rsum * (double)N);
+}
+
+// ------------------------------------------------------------------ init
+// residue[s] = 1, frontier = {s} (algo.h:969-978); dangling source: reserve[s] = 1 (algo.h:961-965)
+__global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int topk_mode) {
+    int q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= d.nq) return;
+    QState z = {};
+    const uint32_t s = (uint32_t)d.src[q];
+    int64_t beg; uint64_t deg;
+    node_row(d, s, beg, deg);
+    if (deg == 0) {
+        d.ppr[(uint64_t)q * d.n + s] = FIX_ONE;
+        z.reserved = FIX_ONE;
+        z.dangling_source = 1;
+    } else {
+        d.residue[(uint64_t)q * d.n + s] = FIX_ONE;
+        if (!topk_mode) {
+            unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
+            d.wl[0][i] = ((uint64_t)q << 32) | s;
+        }
+    }
+    d.qs[q] = z;
+}
+
+// ------------------------------------------------------------------ push: pop
+// One thread per frontier entry (q, v): take the residue, keep alpha of it, cut the
+// out-edges into <=PUSH_SEG slices for k_push_expand (algo.h:983-1002).
+__global__ void __launch_bounds__(BLOCK) k_push_pop(Dev d, int L) {
+    const uint64_t count = d.wl_count[L];
+    const uint64_t *in = d.wl[L & 1];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * BLOCK; base < count; base += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        const bool act = i < count;
+        uint32_t q = 0, nseg = 0;
+        uint64_t res_add = 0, dang = 0, inc = 0, deg = 0;
+        int64_t beg = 0;
+        if (act) {
+            const uint64_t item = in[i];
+            q = (uint32_t)(item >> 32);
+            const uint32_t v = (uint32_t)item;
+            const uint64_t a = (uint64_t)q * d.n + v;
+            const uint64_t r = d.residue[a];
+            d.residue[a] = 0;                                 // algo.h:985
+            const uint64_t keep = mulshift62(r, d.afix);      // v_residue * alpha
+            const uint64_t push = r - keep;                   // (1-alpha) * v_residue
+            node_row(d, v, beg, deg);
+            if (deg == 0) {                                   // algo.h:993-994
+                res_add = keep;
+                dang = push;
+            } else {
+                inc = push / deg;                             // algo.h:1002
+                res_add = keep + (push - inc * deg);          // division remainder stays reserved
+                nseg = (uint32_t)((deg + PUSH_SEG - 1) / PUSH_SEG);
+            }
+            d.ppr[a] += res_add;                              // algo.h:986-989 (only this thread owns (q,v))
+        }
+        // slices -> seg list
+        uint32_t tot;
+        const uint32_t off = wave_excl_scan(nseg, tot);
+        if (tot) {
+            unsigned long long sb = 0;
+            if (lane == 0) sb = atomicAdd(&d.seg_count[L], (unsigned long long)tot);
+            sb = __shfl(sb, 0);
+            if (sb + tot > d.seg_cap) {
+                if (lane == 0) atomicOr(d.err, ERR_SEG_OVERFLOW);
+            } else {
+                for (uint32_t k = 0; k < nseg; k++) {
+                    PushSeg s;
+                    s.ebeg = beg + (int64_t)k * PUSH_SEG;
+                    s.inc = inc;
+                    s.q = q;
+                    const uint64_t left = deg - (uint64_t)k * PUSH_SEG;
+                    s.cnt = left < PUSH_SEG ? (uint32_t)left : PUSH_SEG;
+                    d.seg[sb + off + k] = s;
+                }
+            }
+        }
+        // per-slot accumulators: rsum bookkeeping (algo.h:992), dangling mass, counters
+        const uint32_t q0 = __builtin_amdgcn_readfirstlane(q);
+        if (__all(!act || q == q0)) {
+            const uint64_t sr = wave_sum(res_add), sd = wave_sum(dang);
+            const uint64_t sp = wave_sum(act ? 1 : 0), se = wave_sum(deg);
+            if (lane == 0 && sp) {
+                QState *s = &d.qs[q0];
+                atomicAdd(&s->reserved, (unsigned long long)sr);
+                if (sd) atomicAdd(&s->dang, (unsigned long long)sd);
+                atomicAdd(&s->pops, (unsigned long long)sp);
+                if (se) atomicAdd(&s->relax, (unsigned long long)se);
+                s->levels = (uint32_t)L + 1;
+            }
+        } else if (act) {
+            QState *s = &d.qs[q];
+            atomicAdd(&s->reserved, (unsigned long long)res_add);
+            if (dang) atomicAdd(&s->dang, (unsigned long long)dang);
+            atomicAdd(&s->pops, 1ull);
+            if (deg) atomicAdd(&s->relax, (unsigned long long)deg);
+            s->levels = (uint32_t)L + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ push: expand
+// The roofline kernel.  A block stages 256 edge slices in LDS (first edge, increment,
+// slot, prefix sum of slice lengths), then its threads walk the concatenated edge
+// range: consecutive threads read consecutive col entries (coalesced), add the
+// increment to residue[q][w] with one returning u64 atomic, and the thread whose
+// add carries the residue across w's threshold appends (q, w) to the next frontier
+// (algo.h:1003-1016).  Increments are positive, so exactly one add crosses.
+__global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
+    __shared__ int64_t s_ebeg[BLOCK];
+    __shared__ uint64_t s_inc[BLOCK];
+    __shared__ uint32_t s_q[BLOCK];
+    __shared__ uint32_t s_pref[BLOCK + 1];
+    __shared__ uint32_t s_w[4];
+    uint64_t *out = d.wl[(L + 1) & 1];
+    unsigned long long *out_count = &d.wl_count[L + 1];
+
+    // dangling mass collected by k_push_pop returns to the source (algo.h:994-998)
+    if ((uint64_t)blockIdx.x * BLOCK < (uint64_t)d.nq) {
+        const int q = blockIdx.x * BLOCK + threadIdx.x;
+        bool cross = false;
+        uint64_t item = 0;
+        if (q < d.nq) {
+            const uint64_t dm = d.qs[q].dang;
+            if (dm) {
+                d.qs[q].dang = 0;
+                const uint32_t s = (uint32_t)d.src[q];
+                const uint64_t old = atomicAdd((unsigned long long *)&d.residue[(uint64_t)q * d.n + s],
+                                               (unsigned long long)dm);
+                const uint64_t thr = node_thr(d.t1, d.deg[s]);
+                cross = old < thr && old + dm >= thr;
+                item = ((uint64_t)q << 32) | s;
+            }
+        }
+        wave_append(cross, item, out, out_count, d.wl_cap, d.err, ERR_WL_OVERFLOW);
+    }
+
+    const uint64_t count = d.seg_count[L];
+    for (uint64_t tbase = (uint64_t)blockIdx.x * BLOCK; tbase < count; tbase += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
+        if (i < count) {
+            const PushSeg s = d.seg[i];
+            s_ebeg[threadIdx.x] = s.ebeg;
+            s_inc[threadIdx.x] = s.inc;
+            s_q[threadIdx.x] = s.q;
+            cnt = s.cnt;
+        }
+        uint32_t total;
+        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        __syncthreads();
+        for (uint32_t eb = 0; eb < total; eb += BLOCK) {
+            const uint32_t e = eb + threadIdx.x;
+            bool cross = false;
+            uint64_t item = 0;
+            if (e < total) {
+                uint32_t lo = 0, hi = BLOCK; // largest lo with s_pref[lo] <= e
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                const uint32_t w = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                const uint64_t inc = s_inc[lo];
+                const uint32_t q = s_q[lo];
+                const uint64_t old = atomicAdd((unsigned long long *)&d.residue[(uint64_t)q * d.n + w],
+                                               (unsigned long long)inc);
+                const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                cross = old < thr && old + inc >= thr;
+                item = ((uint64_t)q << 32) | w;
+            }
+            wave_append(cross, item, out, out_count, d.wl_cap, d.err, ERR_WL_OVERFLOW);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ walk allocation
+// One thread per (slot, node): num_s_rw = ceil(r/rsum*N), weight r/num_s_rw
+// (query.h:270,282-287; --opt: query.h:349,363-364), cut into <=WALK_SEG-walk items.
+// grid = (chunks, nq).
+__global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx) {
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    QState *qs = &d.qs[q];
+    const uint64_t rsum_fix = FIX_ONE - qs->reserved;
+    if (rsum_fix == 0) return; // query.h:267-268
+    double check_rsum = fix2d(rsum_fix);
+    if (d.opt) check_rsum *= (1 - d.alpha);                // query.h:349
+    const uint64_t N = (uint64_t)(d.omega * check_rsum);   // query.h:270
+    if (blockIdx.x == 0 && threadIdx.x == 0) qs->n_rw = N;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
+    uint64_t acc_walks = 0, acc_hit = 0;
+    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        const uint32_t v = c * BLOCK + threadIdx.x;
+        uint64_t r = 0, num = 0, incr = 0, rem = 0, icnt = 0, ioff = 0;
+        uint32_t nseg = 0;
+        if (v < (uint32_t)d.n) r = d.residue[slab + v];
+        if (r) {
+            if (d.opt) { // query.h:363-364
+                const uint64_t keep = mulshift62(r, d.afix);
+                d.ppr[slab + v] += keep;
+                r -= keep;
+            }
+            num = walk_count(fix2d(r), check_rsum, N);
+            if (num) {
+                incr = r / num;
+                rem = r - incr * num;
+                nseg = (uint32_t)((num + WALK_SEG - 1) / WALK_SEG);
+                if (with_idx) {
+                    icnt = d.idx_cnt[v];
+                    ioff = d.idx_off[v];
+                    acc_hit += num < icnt ? num : icnt;
+                }
+                acc_walks += num;
+            }
+        }
+        uint32_t tot;
+        const uint32_t off = wave_excl_scan(nseg, tot);
+        if (tot) {
+            unsigned long long sb = 0;
+            if (lane == 0) sb = atomicAdd(d.wit_count, (unsigned long long)tot);
+            sb = __shfl(sb, 0);
+            if (sb + tot > d.wit_cap) {
+                if (lane == 0) atomicOr(d.err, ERR_WIT_OVERFLOW);
+            } else {
+                for (uint32_t k = 0; k < nseg; k++) {
+                    WalkItem w;
+                    w.j0 = (uint64_t)k * WALK_SEG;
+                    const uint64_t left = num - w.j0;
+                    w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
+                    w.idx_pos = ioff + w.j0;
+                    const uint64_t iav = icnt > w.j0 ? icnt - w.j0 : 0;
+                    w.idx_n = iav < w.cnt ? (uint32_t)iav : w.cnt;
+                    w.incr = incr;
+                    w.rem = rem;
+                    w.q = (uint32_t)q;
+                    w.v = v;
+                    d.wit[sb + off + k] = w;
+                }
+            }
+        }
+    }
+    acc_walks = wave_sum(acc_walks);
+    acc_hit = wave_sum(acc_hit);
+    if (lane == 0) {
+        if (acc_walks) atomicAdd(&qs->n_walks, (unsigned long long)acc_walks);
+        if (acc_hit) atomicAdd(&qs->n_hit, (unsigned long long)acc_hit);
+    }
+}
+
+// index sizes are computed on the host (build.h:325-334); this cuts them into items
+__global__ void __launch_bounds__(BLOCK) k_index_alloc(Dev d) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        const uint32_t v = c * BLOCK + threadIdx.x;
+        uint64_t num = 0, ioff = 0;
+        if (v < (uint32_t)d.n) { num = d.idx_cnt[v]; ioff = d.idx_off[v]; }
+        const uint32_t nseg = (uint32_t)((num + WALK_SEG - 1) / WALK_SEG);
+        uint32_t tot;
+        const uint32_t off = wave_excl_scan(nseg, tot);
+        if (tot) {
+            unsigned long long sb = 0;
+            if (lane == 0) sb = atomicAdd(d.wit_count, (unsigned long long)tot);
+            sb = __shfl(sb, 0);
+            if (sb + tot > d.wit_cap) {
+                if (lane == 0) atomicOr(d.err, ERR_WIT_OVERFLOW);
+            } else {
+                for (uint32_t k = 0; k < nseg; k++) {
+                    WalkItem w = {};
+                    w.j0 = (uint64_t)k * WALK_SEG;
+                    const uint64_t left = num - w.j0;
+                    w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
+                    w.idx_pos = ioff + w.j0;
+                    w.v = v;
+                    d.wit[sb + off + k] = w;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ walks
+enum { WALK_TO_PPR = 0, WALK_TO_INDEX = 1 };
+
+// One alpha-terminated walk under the Philox contract (see oracle/fora_oracle.c orc_walk;
+// semantics algo.h:124-142 and, with nzh, algo.h:144-166).
+struct WalkRng {
+    uint32_t w[4];
+};
+__device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64_t j, uint32_t stream,
+                                            uint32_t round, int nzh, uint32_t &steps) {
+    int64_t beg; uint64_t deg;
+    node_row(d, start, beg, deg);
+    if (deg == 0) return (int32_t)start; // algo.h:127-129
+    uint32_t cur = start;
+    uint32_t w[4];
+    for (uint32_t t = 0;; t++) {
+        if ((t & 1u) == 0)
+            philox4x32_10(start, (uint32_t)j,
+                          (uint32_t)((j >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
+                          stream, d.seed_lo, d.seed_hi, w);
+        const uint32_t ws = (t & 1u) ? w[2] : w[0], wm = (t & 1u) ? w[3] : w[1];
+        if (!(nzh && t == 0) && ws < d.alpha32) return (int32_t)cur; // algo.h:131-133
+        if (t) node_row(d, cur, beg, deg);
+        if (deg > 0) // algo.h:134-137
+            cur = (uint32_t)d.col[beg + (int64_t)(((uint64_t)wm * deg) >> 32)];
+        else         // algo.h:138-140
+            cur = start;
+        steps++;
+    }
+}
+
+// A block stages 256 walk items in LDS; thread t runs walks t, t+256, ... of the
+// concatenated walk range (consecutive threads = consecutive walks of one start node).
+// Each lane moves on to its next walk as soon as its current one stops, so lanes do
+// not wait for the longest walk of the wave.
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_walk(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
+    __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
+    __shared__ uint32_t s_q[BLOCK], s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
+    const uint64_t count = *d.wit_count;
+    uint32_t steps = 0;
+    for (uint64_t tbase = (uint64_t)blockIdx.x * BLOCK; tbase < count; tbase += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
+        if (i < count) {
+            const WalkItem w = d.wit[i];
+            s_j0[threadIdx.x] = w.j0; s_pos[threadIdx.x] = w.idx_pos;
+            s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
+            s_q[threadIdx.x] = w.q; s_v[threadIdx.x] = w.v; s_idxn[threadIdx.x] = w.idx_n;
+            cnt = w.cnt;
+        }
+        uint32_t total;
+        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < total; e += BLOCK) {
+            uint32_t lo = 0, hi = BLOCK;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= e) lo = mid; else hi = mid;
+            }
+            const uint32_t jj = e - s_pref[lo];
+            const uint64_t j = s_j0[lo] + jj;
+            const uint32_t v = s_v[lo];
+            if (MODE == WALK_TO_INDEX) {
+                idx_out[s_pos[lo] + jj] = walk_one(d, v, j, 0xFFFFFFFFu, 0, nzh, steps); // build.h:346-353
+            } else {
+                const uint32_t q = s_q[lo];
+                int32_t dest;
+                if (jj < s_idxn[lo]) dest = d.rw_idx[s_pos[lo] + jj];                  // query.h:291-293
+                else dest = walk_one(d, v, j, (uint32_t)d.src[q], round, nzh, steps);   // query.h:298,321
+                atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + (uint32_t)dest],
+                          (unsigned long long)(s_incr[lo] + (j < s_rem[lo] ? 1 : 0)));  // query.h:299,322
+            }
+        }
+        __syncthreads();
+    }
+    const uint64_t ws = wave_sum((uint64_t)steps);
+    if ((threadIdx.x & 63) == 0 && ws) atomicAdd(d.tot_steps, (unsigned long long)ws);
+}
+
+// ------------------------------------------------------------------ epilogue / hooks
+// sum of each slot's ppr slab (mass check); grid = (chunks, nq)
+__global__ void __launch_bounds__(BLOCK) k_ppr_sum(Dev d) {
+    const int q = blockIdx.y;
+    const uint64_t slab = (uint64_t)q * d.n;
+    uint64_t acc = 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK)
+        acc += d.ppr[slab + v];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&d.qs[q].ppr_sum, (unsigned long long)acc);
+}
+
+// stage hook: walk allocation on caller-supplied f64 residues (reference arithmetic)
+__global__ void __launch_bounds__(BLOCK) k_walk_counts_f64(int32_t n, const double *residue, double rsum,
+                                                           double omega, double alpha, int opt,
+                                                           uint64_t *num_s_rw, uint64_t *n_rw) {
+    double check_rsum = rsum;
+    if (opt) check_rsum *= (1 - alpha);
+    const uint64_t N = check_rsum == 0.0 ? 0 : (uint64_t)(omega * check_rsum);
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v == 0) *n_rw = N;
+    if (v >= n) return;
+    double r = residue[v];
+    uint64_t num = 0;
+    if (r > 0 && check_rsum != 0.0) {
+        if (opt) r = r * (1 - alpha);
+        num = walk_count(r, check_rsum, N);
+    }
+    num_s_rw[v] = num;
+}
+
+// stage hook: raw walk endpoints
+__global__ void __launch_bounds__(BLOCK) k_walks_raw(Dev d, uint32_t stream, uint32_t round, int nzh,
+                                                     const int32_t *starts, const uint64_t *js, int64_t count,
+                                                     int32_t *dests) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    uint32_t steps = 0;
+    dests[i] = walk_one(d, (uint32_t)starts[i], js[i], stream, round, nzh, steps);
+}
+
+} // namespace fora

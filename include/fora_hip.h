@@ -1,0 +1,144 @@
+/*
+ * fora_hip.h -- C ABI of the MI355X-native FORA SSPPR engine (libfora_hip.so).
+ *
+ * The reference (wangsibovictor/fora) exposes no plugin / FFI interface; its
+ * seams are C++ free functions that read and write global state from one thread
+ * (SURVEY.md 8b).  Each entry point below names the reference seam it replaces.
+ * Conventions: plain C types only, caller-allocated outputs, return 0 on success
+ * or a negative FORA_E_* code (never throws, never exit()s), one ctx per GPU, a
+ * ctx is used by one host thread at a time.  All host pointers are ordinary
+ * pageable memory; the library copies.
+ *
+ * Arithmetic: residue / reserve / ppr are kept on the device as unsigned 2^-62
+ * fixed point (1.0 == FORA_FIX_ONE) so that every accumulation is an exact,
+ * order-independent integer atomic; double-typed outputs are value * 2^-62.
+ */
+#ifndef FORA_HIP_H
+#define FORA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FORA_FIX_ONE (1ULL << 62)
+#define FORA_STREAM_INDEX 0xFFFFFFFFu
+
+enum {
+    FORA_OK = 0,
+    FORA_E_ARG = -1,      /* bad argument / call order (reference: assert, graph.h:155) */
+    FORA_E_HIP = -2,      /* HIP runtime error, see fora_hip_last_error */
+    FORA_E_NOMEM = -3,    /* device memory */
+    FORA_E_OVERFLOW = -4, /* internal work list overflow / level cap reached */
+    FORA_E_NOGPU = -5     /* no usable gfx950 device */
+};
+
+typedef struct fora_ctx fora_ctx;
+
+/* Per-query counters.  Replaces the globals fora_query_basic updates:
+ * num_total_rw / num_hit_idx (algo.h:39-40), rsum (query.h:843), plus schedule
+ * counters of the level-synchronous push. */
+typedef struct {
+    double rsum;         /* residue mass left by the push, = rsum_fix * 2^-62 (query.h:843,886) */
+    uint64_t rsum_fix;
+    uint64_t n_rw;       /* N = (u64)(omega*rsum') of query.h:270 */
+    uint64_t n_walks;    /* sum of num_s_rw, query.h:287,318 (num_total_rw) */
+    uint64_t n_idx_hit;  /* walks served from the index, query.h:295,306 (num_hit_idx) */
+    uint64_t pops;       /* frontier pops of the push */
+    uint64_t relax;      /* edge relaxations of the push */
+    uint64_t ppr_sum_fix; /* sum of the final ppr vector (== FORA_FIX_ONE when mass is conserved) */
+    int32_t levels;      /* push levels this query was active in */
+    int32_t dangling_source; /* 1: algo.h:961-965 fast path taken */
+} fora_query_stats;
+
+/* Accumulated device timings since the last reset (HIP events on the ctx stream). */
+typedef struct {
+    double push_pop_ms;     /* sum over k_push_pop launches */
+    double push_expand_ms;  /* sum over k_push_expand launches (the roofline kernel) */
+    double walk_alloc_ms;   /* k_walk_alloc */
+    double walk_ms;         /* k_walk */
+    double other_ms;        /* init / reduce / convert kernels + memsets */
+    double batch_ms;        /* whole batches, first launch to last completion */
+    uint64_t push_pop_launches;
+    uint64_t push_expand_launches;
+    uint64_t walk_launches;
+    uint64_t batches;
+    uint64_t pops;          /* totals over all queries since reset */
+    uint64_t relax;
+    uint64_t walks;
+    uint64_t walk_steps;
+    uint64_t levels;        /* levels launched (including speculative empty ones) */
+} fora_timing;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int fora_hip_create(int device, fora_ctx **out);
+void fora_hip_destroy(fora_ctx *ctx);
+const char *fora_hip_last_error(fora_ctx *ctx);
+/* device name / arch string of the ctx's GPU, e.g. "gfx950:sramecc+:xnack-" */
+int fora_hip_device_info(fora_ctx *ctx, char *arch, int arch_len, int *cus, uint64_t *hbm_bytes);
+
+/* ---- graph: replaces Graph::init_graph's in-memory result (graph.h:89-163) --
+ * CSR with per-row file order; m_attr is the m of attribute.txt (graph.h:58-63),
+ * which the parameter formulas use even when it differs from nnz. */
+int fora_hip_set_graph(fora_ctx *ctx, int32_t n, int64_t m_attr, const int64_t *row_ptr,
+                       const int32_t *col);
+
+/* ---- parameters: replaces init_parameter (graph.h:173-183) + fora_setting
+ * (algo.h:455-463); alpha is config.alpha (config.h:27,132). */
+int fora_hip_set_params(fora_ctx *ctx, double alpha, double epsilon, double rmax_scale, int opt,
+                        uint64_t seed);
+/* same, with rmax / omega given directly (tests, --balanced style callers) */
+int fora_hip_set_params_raw(fora_ctx *ctx, double alpha, double rmax, double omega, int opt,
+                            uint64_t seed);
+int fora_hip_get_params(fora_ctx *ctx, double *rmax, double *omega);
+/* queries processed concurrently per launch; 0 = choose from free HBM */
+int fora_hip_set_batch(fora_ctx *ctx, int batch);
+int fora_hip_get_batch(fora_ctx *ctx);
+
+/* ---- walk index: replaces build() (build.h:302-366), rw_idx / rw_idx_info
+ * (algo.h:42-43) and deserialize_idx() (build.h:194-207) ------------------- */
+int fora_hip_index_sizes(fora_ctx *ctx, uint64_t *total, uint64_t *off /*n or NULL*/,
+                         uint64_t *cnt /*n or NULL*/);
+int fora_hip_build_index(fora_ctx *ctx); /* walks on the GPU, index stays in HBM */
+int fora_hip_get_index(fora_ctx *ctx, int32_t *rw_idx, uint64_t len, uint64_t *off, uint64_t *cnt);
+int fora_hip_set_index(fora_ctx *ctx, const int32_t *rw_idx, uint64_t len, const uint64_t *off,
+                       const uint64_t *cnt);
+int fora_hip_clear_index(fora_ctx *ctx);
+
+/* ---- SSPPR: replaces the query() loop over fora_query_basic
+ * (query.h:1471-1476 -> query.h:841-907).  ppr_out: nq*n doubles or NULL
+ * (results then stay in HBM; only stats come back).  with_idx: config.with_rw_idx. */
+int fora_hip_query_batch(fora_ctx *ctx, const int32_t *sources, int nq, int with_idx,
+                         double *ppr_out, fora_query_stats *stats /*nq or NULL*/);
+/* same run, raw fixed-point outputs for bit-exact checks (either may be NULL) */
+int fora_hip_query_batch_fix(fora_ctx *ctx, const int32_t *sources, int nq, int with_idx,
+                             uint64_t *ppr_fix_out, uint64_t *residue_fix_out,
+                             fora_query_stats *stats);
+
+/* ---- top-k: replaces the topk() loop over get_topk -> fora_query_topk_new +
+ * topk_ppr (query.h:1397-1401, 1139-1156, 972-1045; algo.h:592-610), --opt driver.
+ * ids / scores: nq*k, score descending (ties: id ascending), padded with (0, 0.0). */
+int fora_hip_topk_batch(fora_ctx *ctx, const int32_t *sources, int nq, int k, double epsilon,
+                        double rmax_scale, int with_idx, int32_t *ids, double *scores,
+                        int32_t *rounds /*nq or NULL*/);
+
+/* ---- stage hooks (same device code as the paths above, exposed for parity tests) */
+/* forward push only (forward_local_update_linear, algo.h:954-1018) */
+int fora_hip_push_batch(fora_ctx *ctx, const int32_t *sources, int nq, uint64_t *reserve_fix_out,
+                        uint64_t *residue_fix_out, fora_query_stats *stats);
+/* walk allocation in the reference's f64 arithmetic (query.h:270,282 / :349,:364):
+ * residue: n doubles (<= 0 entries get 0 walks); returns N and num_s_rw[n]. */
+int fora_hip_walk_counts(fora_ctx *ctx, const double *residue, double rsum, uint64_t *num_s_rw,
+                         uint64_t *n_rw);
+/* endpoints of `count` walks under the Philox contract (random_walk /
+ * random_walk_no_zero_hop, algo.h:124-166) */
+int fora_hip_walks(fora_ctx *ctx, uint32_t stream, uint32_t round, int no_zero_hop,
+                   const int32_t *starts, const uint64_t *js, int64_t count, int32_t *dests);
+
+/* ---- measurement ----------------------------------------------------------- */
+int fora_hip_reset_timing(fora_ctx *ctx);
+int fora_hip_get_timing(fora_ctx *ctx, fora_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

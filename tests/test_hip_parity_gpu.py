@@ -1,0 +1,198 @@
+"""GPU parity tests, all through the C ABI (fora_amd.Engine -> libfora_hip.so).
+
+Bars:
+  * vs the oracle TWIN (same schedule, same fixed point): bit-exact on reserve,
+    residue, rsum, counters, walk counts, walk endpoints, index contents, final ppr.
+  * vs the oracle in the REFERENCE's arithmetic and FIFO order: walk allocation and
+    walk endpoints bit-exact on the same inputs; refined ppr within a stated L-inf
+    tolerance; both within the epsilon guarantee of exact PPR.
+"""
+import numpy as np
+import pytest
+
+from conftest import pick_sources
+
+pytestmark = pytest.mark.gpu
+SEED = 0x464F5241
+
+
+def _load(engine, g, **kw):
+    engine.clear_index()
+    engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+    engine.set_params(seed=SEED, **kw)
+    return engine.get_params()
+
+
+@pytest.mark.parametrize("gname", ["tiny", "tiny_dangling", "small", "small_dangling"])
+def test_push_bit_exact_vs_twin(engine, oracle, request, gname):
+    g = request.getfixturevalue(gname)
+    rmax, omega = _load(engine, g, epsilon=0.5)
+    assert (rmax, omega) == oracle.fora_setting(g.n, g.m, 0.5)
+    srcs = np.concatenate([pick_sources(g, 6, 21), pick_sources(g, 2, 22, want_dangling=True)])
+    rsv, res, st = engine.push(srcs)
+    for i, s in enumerate(srcs):
+        t = oracle.twin_push(g, int(s), rmax)
+        assert (rsv[i] == t["reserve"]).all()
+        assert (res[i] == t["residue"]).all()
+        assert st[i]["rsum_fix"] == t["rsum_fix"]
+        assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+        assert int(rsv[i].sum()) + int(res[i].sum()) == oracle.FIX_ONE
+        assert st[i]["dangling_source"] == int(g.deg[s] == 0)
+
+
+@pytest.mark.parametrize("opt", [False, True])
+def test_walk_allocation_bit_exact_vs_reference_arithmetic(engine, oracle, small, opt):
+    """num_s_rw from the FIFO oracle's f64 residues: query.h:282 / :364, same device code
+    (fora::walk_count) the product path uses."""
+    g = small
+    rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
+    assert (rmax, omega) == oracle.fora_setting(g.n, g.m, 0.5, opt=opt)
+    for s in pick_sources(g, 3, 23):
+        p = oracle.push_fifo(g, int(s), rmax)
+        N, cnt = oracle.walk_counts(p, omega, opt=opt)
+        dense = np.zeros(g.n, dtype=np.uint64)
+        dense[p["residue_occur"]] = cnt
+        N2, got = engine.walk_counts(p["residue"], p["rsum"])
+        assert N2 == N
+        assert (got == dense).all()
+
+
+def test_walk_endpoints_bit_exact(engine, oracle, small_dangling):
+    g = small_dangling
+    _load(engine, g, epsilon=0.5)
+    rng = np.random.Generator(np.random.PCG64(24))
+    starts = rng.integers(0, g.n, size=4000).astype(np.int32)
+    js = rng.integers(0, 1 << 44, size=4000).astype(np.uint64)
+    for nzh in (False, True):
+        for rnd, stream in ((0, 12345), (3, oracle.STREAM_INDEX)):
+            got = engine.walks(stream, rnd, starts, js, no_zero_hop=nzh)
+            want = np.array([oracle.walk(g, SEED, stream, rnd, int(v), int(j), no_zero_hop=nzh)
+                             for v, j in zip(starts, js)], dtype=np.int32)
+            assert (got == want).all()
+
+
+@pytest.mark.parametrize("opt", [False, True])
+@pytest.mark.parametrize("gname", ["tiny_dangling", "small"])
+def test_query_bit_exact_vs_twin(engine, oracle, request, gname, opt):
+    g = request.getfixturevalue(gname)
+    rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
+    srcs = np.concatenate([pick_sources(g, 4, 25), pick_sources(g, 1, 26, want_dangling=True)])
+    ppr, res, st = engine.query_fix(srcs)
+    for i, s in enumerate(srcs):
+        want, wres, wst = oracle.twin_query(g, int(s), rmax, omega, opt=opt, seed=SEED)
+        assert (res[i] == wres).all()
+        assert (ppr[i] == want).all()
+        assert st[i]["n_walks"] == wst["n_walks"] and st[i]["n_idx_hit"] == 0
+        assert st[i]["ppr_sum_fix"] == int(want.sum())
+        if wst["rsum_fix"]:
+            assert st[i]["ppr_sum_fix"] == oracle.FIX_ONE  # mass conserved exactly
+
+
+@pytest.mark.parametrize("opt", [False, True])
+def test_index_build_and_indexed_query_bit_exact(engine, oracle, small, opt):
+    g = small
+    rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
+    total, off, cnt = engine.index_sizes()
+    t2, off2, cnt2 = oracle.index_sizes(g, rmax, omega, opt=opt)
+    assert total == t2 and (off == off2).all() and (cnt == cnt2).all()   # build.h:325-334
+    engine.build_index()
+    rw, o3, c3 = engine.get_index()
+    want_rw, _, _ = oracle.build_index(g, SEED, rmax, omega, opt=opt)
+    assert (rw == want_rw).all()                                        # build.h:344-354 under Philox
+    srcs = pick_sources(g, 4, 27)
+    ppr, res, st = engine.query_fix(srcs, with_idx=True)
+    for i, s in enumerate(srcs):
+        want, _, wst = oracle.twin_query(g, int(s), rmax, omega, opt=opt, seed=SEED, index=(want_rw, off2, cnt2))
+        assert (ppr[i] == want).all()
+        assert st[i]["n_idx_hit"] == wst["n_idx_hit"] == st[i]["n_walks"]  # 100 % index hit
+    # an index that is too short forces the online top-up branch (query.h:290-300)
+    half = (cnt2 // 2).astype(np.uint64)
+    engine.set_index(want_rw, off2, half)
+    ppr, _, st = engine.query_fix(srcs, with_idx=True)
+    for i, s in enumerate(srcs):
+        want, _, wst = oracle.twin_query(g, int(s), rmax, omega, opt=opt, seed=SEED, index=(want_rw, off2, half))
+        assert (ppr[i] == want).all()
+        assert st[i]["n_idx_hit"] == wst["n_idx_hit"] < st[i]["n_walks"]
+    engine.clear_index()
+
+
+@pytest.mark.parametrize("opt", [False, True])
+def test_vs_reference_order_oracle_and_exact_ppr(engine, oracle, small, opt):
+    """The float side of the bar: |ppr_gpu - ppr_fifo_oracle|_inf <= 1e-3 (two valid push
+    states + independent Monte-Carlo noise at n=32k), and the FORA guarantee
+    |est - pi| <= eps*pi wherever pi >= 1/n, against power iteration."""
+    g = small
+    eps = 0.5
+    rmax, omega = _load(engine, g, epsilon=eps, opt=opt)
+    srcs = pick_sources(g, 3, 28)
+    ppr, st = engine.query(srcs)
+    for i, s in enumerate(srcs):
+        ref, rst = oracle.query(g, int(s), rmax, omega, opt=opt, seed=SEED)
+        exact = oracle.power_iteration(g, int(s))
+        assert abs(ppr[i].sum() - 1) < 1e-12
+        assert np.abs(ppr[i] - ref).max() <= 1e-3
+        big = exact >= 1.0 / g.n
+        assert (np.abs(ppr[i] - exact)[big] / exact[big]).max() <= eps
+        # reserve side: push states differ by schedule only
+        assert abs(st[i]["rsum"] - rst["rsum"]) < 0.05
+
+
+def test_batching_and_determinism(engine, oracle, small):
+    """Results do not depend on batch size, slot position, or run (integer atomics)."""
+    g = small
+    _load(engine, g, epsilon=0.5)
+    srcs = pick_sources(g, 12, 29)
+    engine.set_batch(12)
+    a, _, _ = engine.query_fix(srcs, want_residue=False)
+    engine.set_batch(5)
+    b, _, _ = engine.query_fix(srcs[::-1].copy(), want_residue=False)
+    engine.set_batch(0)
+    assert (a == b[::-1]).all()
+    c, _, _ = engine.query_fix(srcs, want_residue=False)
+    assert (a == c).all()
+
+
+def test_error_behaviour(engine, oracle, tiny):
+    import fora_amd
+    g = tiny
+    _load(engine, g, epsilon=0.5)
+    with pytest.raises(fora_amd.ForaError):
+        engine.query(np.array([g.n], dtype=np.int32))            # id >= n (graph.h:155)
+    with pytest.raises(fora_amd.ForaError):
+        engine.query(np.array([-1], dtype=np.int32))
+    with pytest.raises(fora_amd.ForaError):
+        engine.query(np.array([0], dtype=np.int32), with_idx=True)  # no index loaded
+    bad = g.col.copy()
+    bad[0] = g.n
+    with pytest.raises(fora_amd.ForaError):
+        engine.set_graph(g.n, g.m, g.row_ptr, bad)
+    _load(engine, g, epsilon=0.5)
+    out, st = engine.query(np.zeros(0, dtype=np.int32))          # empty batch is fine
+    assert out.shape == (0, g.n)
+
+
+def test_full_size_webstanford_properties(engine, oracle):
+    """BASELINE size (n=281 904, m=2 312 497): properties that need no oracle run --
+    exact mass conservation per query, exit condition of the push, determinism."""
+    from fora_amd import synth
+    n, m, row_ptr, col = synth.preset("webstanford")
+    engine.clear_index()
+    engine.set_graph(n, m, row_ptr, col)
+    engine.set_params(epsilon=0.5, seed=SEED)
+    rmax, omega = engine.get_params()
+    assert (rmax, omega) == oracle.fora_setting(n, m, 0.5)
+    srcs = synth.query_set(n, 64, 7)
+    ppr, res, st = engine.query_fix(srcs)
+    deg = np.diff(row_ptr)
+    t1 = int(np.ceil(np.ldexp(rmax, 62)))
+    for i in range(len(srcs)):
+        assert st[i]["ppr_sum_fix"] == 1 << 62
+        assert int(ppr[i].sum()) == 1 << 62
+        assert (res[i].astype(object)[:2000] < (t1 * deg[:2000]).astype(object)).all()
+        assert int(res[i].sum()) == st[i]["rsum_fix"]
+    ppr2, _, _ = engine.query_fix(srcs[:8], want_residue=False)
+    assert (ppr2 == ppr[:8]).all()
+    # one query against the twin at full size (about a second of CPU)
+    g = oracle.Graph(n, m, row_ptr, col)
+    want, _, _ = oracle.twin_query(g, int(srcs[0]), rmax, omega, seed=SEED)
+    assert (ppr[0] == want).all()
