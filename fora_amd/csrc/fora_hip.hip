@@ -61,6 +61,12 @@ struct fora_ctx {
     QState *d_qs = nullptr;
     int32_t *d_src = nullptr;
     uint32_t *d_err = nullptr;
+    uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
+    uint8_t *d_active = nullptr;
+    unsigned long long *d_above = nullptr;
+    int32_t *d_topk_ids = nullptr;
+    double *d_topk_sc = nullptr;
+    int topk_cap = 0;
     unsigned long long *h_pinned = nullptr; // [MAX_LEVELS + 2] frontier sizes read back
     std::vector<QState> h_qs;
 
@@ -103,6 +109,8 @@ void free_index(fora_ctx *c) {
 void free_workspace(fora_ctx *c) {
     dfree(c->d_residue); dfree(c->d_ppr); dfree(c->d_wl[0]); dfree(c->d_wl[1]); dfree(c->d_scratch);
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
+    dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+    c->topk_cap = 0;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     c->h_pinned = nullptr;
     c->B = 0;
@@ -160,7 +168,9 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     return FORA_OK;
 }
 
-Dev make_dev(fora_ctx *c, int nq, bool with_idx) {
+Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega = -1) {
+    if (rmax < 0) rmax = c->rmax;
+    if (omega < 0) omega = c->omega;
     Dev d{};
     d.n = c->n; d.nq = nq;
     d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col; d.deg = c->d_deg;
@@ -174,11 +184,11 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx) {
     d.tot_steps = d.wit_count + 1;
     d.qs = c->d_qs; d.src = c->d_src; d.err = c->d_err;
     d.afix = (uint64_t)std::ldexp(c->alpha, 62);
-    double t = std::ceil(std::ldexp(c->rmax, 62));
+    double t = std::ceil(std::ldexp(rmax, 62));
     d.t1 = t >= 9223372036854775808.0 ? (~0ull >> 1) : (t < 1.0 ? 1 : (uint64_t)t);
     d.alpha32 = (uint32_t)(c->alpha * 4294967296.0);
     d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
-    d.alpha = c->alpha; d.omega = c->omega; d.opt = c->opt;
+    d.alpha = c->alpha; d.omega = omega; d.opt = c->opt;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;
 }
@@ -230,7 +240,7 @@ int check_dev_err(fora_ctx *c) {
 // Level loop of the push for the slots already initialised (frontier of level 0 in wl[0],
 // its size in wl_count[0]).  Launches run ahead of the host by SPEC levels: an empty
 // level costs two near-empty launches, a host round trip per level would cost more.
-int run_push_levels(fora_ctx *c, const Dev &d) {
+int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     constexpr int SPEC = 3;
     hipEvent_t done[SPEC + 1];
     for (auto &e : done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -256,6 +266,7 @@ int run_push_levels(fora_ctx *c, const Dev &d) {
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     for (auto &ev : done) (void)hipEventDestroy(ev);
+    if (levels_run) *levels_run = (uint64_t)L + 1;
     if (rc == FORA_OK && e != hipSuccess) rc = fail(c, FORA_E_HIP, std::string("push: ") + hipGetErrorString(e));
     if (rc == FORA_OK) {
         e = hipGetLastError();
@@ -294,7 +305,8 @@ int run_query_batch(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, 
     if (!(flags & RUN_PUSH_ONLY)) {
         const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
         h = ev_begin(c, 2);
-        hipLaunchKernelGGL(k_walk_alloc, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0);
+        hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
+                           (const uint8_t *)nullptr, (uint64_t *)nullptr);
         ev_end(c, h);
         h = ev_begin(c, 3);
         hipLaunchKernelGGL(k_walk<WALK_TO_PPR>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, 0u,
@@ -655,8 +667,130 @@ int fora_hip_walks(fora_ctx *c, uint32_t stream_id, uint32_t round, int no_zero_
     return FORA_OK;
 }
 
-int fora_hip_topk_batch(fora_ctx *c, const int32_t *, int, int, double, double, int, int32_t *, double *, int32_t *) {
-    return fail(c, FORA_E_ARG, "topk: not implemented yet");
+// top-k driver: fora_query_topk_new (query.h:972-1045) for a batch of slots.  All active slots
+// are in the same round, so delta / rmax / omega are uniform per round; finished slots drop out.
+int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                        int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
+    if (!c) return FORA_E_ARG;
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha, seed)");
+    if (k == 0) k = 500; // query.h:975
+    if (nq < 0 || (nq && (!sources || !ids || !scores))) return fail(c, FORA_E_ARG, "bad arguments");
+    if (k < 2 || k >= c->n - 1) return fail(c, FORA_E_ARG, "k out of range (query.h:1317-1318)");
+    if (k > SEL_MAXK) return fail(c, FORA_E_ARG, "k > 1024 not supported");
+    if (!(epsilon > 0) || !(rmax_scale >= 0)) return fail(c, FORA_E_ARG, "bad epsilon / rmax_scale");
+    if (with_idx && !c->have_index) return fail(c, FORA_E_ARG, "with_idx without an index");
+    for (int i = 0; i < nq; i++)
+        if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    const double n_d = (double)c->n;
+    const double min_delta = 1.0 / c->n;           // query.h:974
+    const double init_delta = 1.0 / k / 10;        // query.h:976
+    const double pfail = 1.0 / c->n / c->n;        // query.h:977
+    const long long m = c->m_attr;
+    (void)n_d;
+    // omega of the last possible round bounds the walk work list
+    const double omega_max = (2 + epsilon) * log(2 / pfail) / min_delta / epsilon / epsilon;
+    int rc = ensure_workspace(c, nq, omega_max);
+    if (rc) return rc;
+    const uint64_t n = (uint64_t)c->n;
+    if (!c->d_ppr2) {
+        const uint64_t slab = (uint64_t)c->B * n;
+        HIPCHK(c, hipMalloc(&c->d_ppr2, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_cursor, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_active, (size_t)c->B));
+        HIPCHK(c, hipMalloc(&c->d_above, (size_t)c->B * 8));
+    }
+    if (c->topk_cap < c->B * k) {
+        dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+        HIPCHK(c, hipMalloc(&c->d_topk_ids, (size_t)c->B * k * 4));
+        HIPCHK(c, hipMalloc(&c->d_topk_sc, (size_t)c->B * k * 8));
+        c->topk_cap = c->B * k;
+    }
+    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    std::vector<uint8_t> active;
+    std::vector<unsigned long long> above;
+    for (int b0 = 0; b0 < nq; b0 += c->B) {
+        const int nb = std::min(c->B, nq - b0);
+        const int hb = ev_begin(c, 5);
+        rc = reset_batch_state(c, nb, sources + b0);
+        if (rc) return rc;
+        if (with_idx) HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (uint64_t)nb * n * 8, c->stream)); // query.h:997-998
+        Dev d = make_dev(c, nb, with_idx != 0);
+        hipLaunchKernelGGL(k_init_batch, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
+        active.assign((size_t)nb, 1);
+        for (int i = 0; i < nb; i++) // dangling source: query.h:1007-1011, one round, ppr = e_s
+            if (c->h_row_ptr[sources[b0 + i] + 1] == c->h_row_ptr[sources[b0 + i]]) active[i] = 0;
+        std::vector<int32_t> nround((size_t)nb, 1);
+        // ppr2 := reserve for every slot once (covers dangling sources)
+        hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
+                           (const uint8_t *)nullptr);
+        double delta = init_delta;
+        int round = 0;
+        while (delta >= min_delta) { // query.h:1001
+            bool any = false;
+            for (int i = 0; i < nb; i++) any |= active[i] != 0;
+            if (!any) break;
+            round++;
+            // fora_topk_setting, algo.h:466-474
+            double rmax = epsilon * sqrt(delta / 3 / m / log(2 / pfail));
+            rmax *= sqrt(1.0 * m * rmax) * rmax_scale * 3;
+            const double omega = (2 + epsilon) * log(2 / pfail) / delta / epsilon / epsilon;
+            for (int i = 0; i < nb; i++) if (active[i]) nround[i] = round;
+            HIPCHK(c, hipMemcpyAsync(c->d_active, active.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_above, 0, (size_t)nb * 8, c->stream));
+            d = make_dev(c, nb, with_idx != 0, rmax, omega);
+            int h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, d, (const uint8_t *)c->d_active);
+            ev_end(c, h);
+            rc = run_push_levels(c, d); // algo.h:1020-1093
+            if (rc) return rc;
+            // compute_ppr_with_fwdidx_topk, query.h:521-636, into ppr2
+            h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
+                               (const uint8_t *)c->d_active);
+            ev_end(c, h);
+            Dev dw = d;
+            dw.ppr = c->d_ppr2;
+            h = ev_begin(c, 2);
+            hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
+                               (const uint8_t *)c->d_active, c->d_cursor);
+            ev_end(c, h);
+            h = ev_begin(c, 3);
+            hipLaunchKernelGGL(k_walk<WALK_TO_PPR>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, dw, (uint32_t)round,
+                               with_idx ? 1 : 0, (int32_t *)nullptr);
+            ev_end(c, h);
+            const double T = (1 + epsilon) * delta; // query.h:1030
+            h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,
+                               (const uint8_t *)c->d_active, T, c->d_above);
+            ev_end(c, h);
+            above.assign((size_t)nb, 0);
+            HIPCHK(c, hipMemcpyAsync(above.data(), c->d_above, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+            rc = check_dev_err(c);
+            if (rc) return rc;
+            for (int i = 0; i < nb; i++)
+                if (active[i] && (above[i] >= (unsigned long long)k || delta <= min_delta)) active[i] = 0;
+            if (delta <= min_delta) break;
+            delta = std::max(min_delta, delta / 4.0); // query.h:1041
+        }
+        // topk_ppr, algo.h:592-610
+        Dev ds = make_dev(c, nb, false);
+        ds.ppr = c->d_ppr2;
+        int h = ev_begin(c, 4);
+        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc);
+        ev_end(c, h);
+        ev_end(c, hb);
+        HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(scores + (size_t)b0 * k, c->d_topk_sc, (size_t)nb * k * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("topk: ") + hipGetErrorString(e));
+        ev_collect(c);
+        if (rounds) for (int i = 0; i < nb; i++) rounds[b0 + i] = nround[i];
+    }
+    return FORA_OK;
 }
 
 int fora_hip_reset_timing(fora_ctx *c) {

@@ -350,42 +350,62 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 }
 
 // ------------------------------------------------------------------ walk allocation
-// One thread per (slot, node): num_s_rw = ceil(r/rsum*N), weight r/num_s_rw
-// (query.h:270,282-287; --opt: query.h:349,363-364), cut into <=WALK_SEG-walk items.
-// grid = (chunks, nq).
-__global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx) {
+// One thread per (slot, node): num_s_rw and the weight r/num_s_rw, cut into <=WALK_SEG-walk
+// items.  grid = (chunks, nq).
+//   ALLOC_QUERY: num_s_rw = ceil(r/rsum*N)  (query.h:270,282-287; --opt: query.h:349,363-364)
+//   ALLOC_TOPK : num_s_rw = ceil(r*omega), index consumed through a per-node cursor so walks
+//                are never reused across rounds (query.h:558-611; online: query.h:616-632)
+enum { ALLOC_QUERY = 0, ALLOC_TOPK = 1 };
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const uint8_t *active,
+                                                      uint64_t *cursor) {
     const int q = blockIdx.y;
     const int lane = threadIdx.x & 63;
+    if (MODE == ALLOC_TOPK && !active[q]) return;
     QState *qs = &d.qs[q];
     const uint64_t rsum_fix = FIX_ONE - qs->reserved;
-    if (rsum_fix == 0) return; // query.h:267-268
+    if (rsum_fix == 0) return; // query.h:267-268 / :535-536
     double check_rsum = fix2d(rsum_fix);
-    if (d.opt) check_rsum *= (1 - d.alpha);                // query.h:349
-    const uint64_t N = (uint64_t)(d.omega * check_rsum);   // query.h:270
-    if (blockIdx.x == 0 && threadIdx.x == 0) qs->n_rw = N;
+    uint64_t N = 0;
+    if (MODE == ALLOC_QUERY) {
+        if (d.opt) check_rsum *= (1 - d.alpha);       // query.h:349
+        N = (uint64_t)(d.omega * check_rsum);         // query.h:270
+        if (blockIdx.x == 0 && threadIdx.x == 0) qs->n_rw = N;
+    }
+    const bool split = MODE == ALLOC_QUERY ? d.opt != 0 : with_idx != 0;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
     uint64_t acc_walks = 0, acc_hit = 0;
     for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
         const uint32_t v = c * BLOCK + threadIdx.x;
-        uint64_t r = 0, num = 0, incr = 0, rem = 0, icnt = 0, ioff = 0;
+        uint64_t r = 0, num = 0, incr = 0, rem = 0, iav = 0, ipos = 0;
         uint32_t nseg = 0;
         if (v < (uint32_t)d.n) r = d.residue[slab + v];
         if (r) {
-            if (d.opt) { // query.h:363-364
+            if (split) { // query.h:363-364 / query.h:561-567
                 const uint64_t keep = mulshift62(r, d.afix);
                 d.ppr[slab + v] += keep;
                 r -= keep;
             }
-            num = walk_count(fix2d(r), check_rsum, N);
+            if (MODE == ALLOC_QUERY) num = walk_count(fix2d(r), check_rsum, N);
+            else num = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618
             if (num) {
                 incr = r / num;
                 rem = r - incr * num;
                 nseg = (uint32_t)((num + WALK_SEG - 1) / WALK_SEG);
                 if (with_idx) {
-                    icnt = d.idx_cnt[v];
-                    ioff = d.idx_off[v];
-                    acc_hit += num < icnt ? num : icnt;
+                    const uint64_t icnt = d.idx_cnt[v];
+                    ipos = d.idx_off[v];
+                    if (MODE == ALLOC_TOPK) { // query.h:575-603
+                        const uint64_t used = cursor[slab + v];
+                        iav = icnt - used;
+                        if (iav > num) iav = num;
+                        cursor[slab + v] = used + iav;
+                        ipos += used;
+                    } else {
+                        iav = num < icnt ? num : icnt;
+                    }
+                    acc_hit += iav;
                 }
                 acc_walks += num;
             }
@@ -404,9 +424,9 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx) {
                     w.j0 = (uint64_t)k * WALK_SEG;
                     const uint64_t left = num - w.j0;
                     w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
-                    w.idx_pos = ioff + w.j0;
-                    const uint64_t iav = icnt > w.j0 ? icnt - w.j0 : 0;
-                    w.idx_n = iav < w.cnt ? (uint32_t)iav : w.cnt;
+                    w.idx_pos = ipos + w.j0;
+                    const uint64_t a = iav > w.j0 ? iav - w.j0 : 0;
+                    w.idx_n = a < w.cnt ? (uint32_t)a : w.cnt;
                     w.incr = incr;
                     w.rem = rem;
                     w.q = (uint32_t)q;
@@ -421,6 +441,170 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx) {
     if (lane == 0) {
         if (acc_walks) atomicAdd(&qs->n_walks, (unsigned long long)acc_walks);
         if (acc_hit) atomicAdd(&qs->n_hit, (unsigned long long)acc_hit);
+    }
+}
+
+// ------------------------------------------------------------------ top-k support
+// Round frontier of the incremental push (algo.h:1020-1093): every node of an active slot
+// whose residue is at/over this round's threshold.  grid = (chunks, nq).
+__global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *active) {
+    const int q = blockIdx.y;
+    if (!active[q]) return;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        const uint32_t v = c * BLOCK + threadIdx.x;
+        bool in = false;
+        if (v < (uint32_t)d.n) {
+            const uint64_t r = d.residue[slab + v];
+            in = r && r >= node_thr(d.t1, d.deg[v]);
+        }
+        wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
+    }
+}
+
+// ppr := reserve for active slots (compute_ppr_with_reserve, query.h:243-253)
+__global__ void __launch_bounds__(BLOCK) k_copy_slab(int32_t n, const uint64_t *src, uint64_t *dst,
+                                                     const uint8_t *active) {
+    const int q = blockIdx.y;
+    if (active && !active[q]) return;
+    const uint64_t slab = (uint64_t)q * n;
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)n; v += (uint64_t)gridDim.x * BLOCK)
+        dst[slab + v] = src[slab + v];
+}
+
+// stop test of query.h:1030: kth_ppr >= (1+eps)*delta  <=>  at least k entries >= it
+__global__ void __launch_bounds__(BLOCK) k_count_above(Dev d, const uint8_t *active, double T,
+                                                       unsigned long long *counts) {
+    const int q = blockIdx.y;
+    if (!active[q]) return;
+    const uint64_t slab = (uint64_t)q * d.n;
+    uint64_t acc = 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK)
+        acc += fix2d(d.ppr[slab + v]) >= T;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&counts[q], (unsigned long long)acc);
+}
+
+// topk_ppr (algo.h:592-610): the k largest entries of a slot's ppr slab, score descending,
+// ties by ascending id, padded with (0, 0.0).  One 1024-thread block per slot: 8-bit radix
+// select of the k-th value (LDS histograms), ordered compaction, bitonic sort in LDS.
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAXK = 1024;
+__global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32_t *ids, double *scores) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint64_t s_key[SEL_MAXK];
+    __shared__ uint32_t s_id[SEL_MAXK];
+    __shared__ uint32_t s_scan[SEL_THREADS / 64];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_need, s_base_gt, s_base_eq;
+    const int q = blockIdx.x;
+    const uint64_t *p = d.ppr + (uint64_t)q * d.n;
+    const uint32_t n = (uint32_t)d.n;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // ---- radix select: value of the k-th largest (0 if fewer than k positive entries)
+    if (tid == 0) { s_prefix = 0; s_need = (uint32_t)k; }
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const uint64_t prefix = s_prefix;
+        const uint64_t himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for (uint32_t v = tid; v < n; v += SEL_THREADS) {
+            const uint64_t x = p[v];
+            if ((x & himask) == prefix) atomicAdd(&s_hist[(x >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t need = s_need, b = 255;
+            for (;; b--) {
+                const uint32_t c = s_hist[b];
+                if (c >= need || b == 0) break;
+                need -= c;
+            }
+            s_need = need; // rank wanted inside bucket b (may exceed its size only when b == 0)
+            s_prefix = prefix | ((uint64_t)b << shift);
+        }
+        __syncthreads();
+    }
+    const uint64_t vk = s_prefix; // k-th largest value (0 when fewer than k positive entries)
+    // ---- ordered compaction: all entries > vk, then the first `need` ids with value == vk (> 0)
+    if (tid == 0) { s_base_gt = 0; s_base_eq = 0; }
+    __syncthreads();
+    const uint32_t need_eq = vk ? s_need : 0;
+    uint32_t n_gt_total = 0;
+    for (uint32_t base = 0; base < n; base += SEL_THREADS) {
+        const uint32_t v = base + tid;
+        const uint64_t x = v < n ? p[v] : 0;
+        const bool gt = x > vk, eq = vk && x == vk;
+        // block-ordered ranks of gt and eq flags
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        const uint32_t rg = __popcll(mg & ((1ull << lane) - 1)), re = __popcll(me & ((1ull << lane) - 1));
+        if (lane == 0) s_scan[wid] = (uint32_t)__popcll(mg) | ((uint32_t)__popcll(me) << 16);
+        __syncthreads();
+        uint32_t og = 0, oe = 0, tg = 0, te = 0;
+        for (int w = 0; w < SEL_THREADS / 64; w++) {
+            const uint32_t c = s_scan[w];
+            if (w < wid) { og += c & 0xFFFF; oe += c >> 16; }
+            tg += c & 0xFFFF; te += c >> 16;
+        }
+        const uint32_t bg = s_base_gt, be = s_base_eq;
+        if (gt) { const uint32_t pos = bg + og + rg; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = v; } }
+        __syncthreads();
+        if (tid == 0) { s_base_gt = bg + tg; s_base_eq = be + te; }
+        (void)re; (void)oe;
+        __syncthreads();
+        n_gt_total = s_base_gt;
+    }
+    // entries equal to vk, lowest ids first, placed after the greater ones
+    if (tid == 0) s_base_eq = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n && need_eq; base += SEL_THREADS) {
+        const uint32_t v = base + tid;
+        const uint64_t x = v < n ? p[v] : 0;
+        const bool eq = x == vk;
+        const unsigned long long me = __ballot(eq);
+        const uint32_t re = __popcll(me & ((1ull << lane) - 1));
+        if (lane == 0) s_scan[wid] = (uint32_t)__popcll(me);
+        __syncthreads();
+        uint32_t oe = 0, te = 0;
+        for (int w = 0; w < SEL_THREADS / 64; w++) { if (w < wid) oe += s_scan[w]; te += s_scan[w]; }
+        const uint32_t be = s_base_eq;
+        if (eq) {
+            const uint32_t rank = be + oe + re;
+            if (rank < need_eq) { const uint32_t pos = n_gt_total + rank; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = v; } }
+        }
+        __syncthreads();
+        if (tid == 0) s_base_eq = be + te;
+        __syncthreads();
+        if (s_base_eq >= need_eq) break;
+    }
+    __syncthreads();
+    uint32_t have = n_gt_total + (need_eq < s_base_eq ? need_eq : s_base_eq);
+    if (have > (uint32_t)k) have = (uint32_t)k;
+    // ---- bitonic sort of SEL_MAXK slots by (value desc, id asc); empty slots sort last
+    for (uint32_t i = tid; i < (uint32_t)SEL_MAXK; i += SEL_THREADS)
+        if (i >= have) { s_key[i] = 0; s_id[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= (uint32_t)SEL_MAXK; sz <<= 1) {
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < (uint32_t)SEL_MAXK; i += SEL_THREADS) {
+                const uint32_t j = i ^ st;
+                if (j > i) {
+                    const uint64_t ki = s_key[i], kj = s_key[j];
+                    const uint32_t ii = s_id[i], ij = s_id[j];
+                    const bool i_first = ki > kj || (ki == kj && ii < ij); // i should come before j
+                    const bool up = (i & sz) == 0;
+                    if (up ? !i_first : i_first) { s_key[i] = kj; s_key[j] = ki; s_id[i] = ij; s_id[j] = ii; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < (uint32_t)k; i += SEL_THREADS) {
+        const bool ok = i < have;
+        ids[(uint64_t)q * k + i] = ok ? (int32_t)s_id[i] : 0;
+        scores[(uint64_t)q * k + i] = ok ? fix2d(s_key[i]) : 0.0;
     }
 }
 

@@ -196,3 +196,48 @@ def test_full_size_webstanford_properties(engine, oracle):
     g = oracle.Graph(n, m, row_ptr, col)
     want, _, _ = oracle.twin_query(g, int(srcs[0]), rmax, omega, seed=SEED)
     assert (ppr[0] == want).all()
+
+
+@pytest.mark.parametrize("with_idx", [False, True])
+@pytest.mark.parametrize("gname", ["small", "small_dangling"])
+def test_topk_bit_exact_vs_twin(engine, oracle, request, gname, with_idx):
+    """fora_query_topk_new + topk_ppr (query.h:972-1045, algo.h:592-610), --opt driver."""
+    g = request.getfixturevalue(gname)
+    k, eps = 50, 0.5
+    rmax, omega = _load(engine, g, epsilon=eps, opt=True)
+    index = None
+    if with_idx:
+        engine.build_index()
+        index = engine.get_index()
+        want_rw, _, _ = oracle.build_index(g, SEED, rmax, omega, opt=True)
+        assert (index[0] == want_rw).all()
+    srcs = np.concatenate([pick_sources(g, 5, 31), pick_sources(g, 1, 32, want_dangling=True)])
+    ids, sc, rounds = engine.topk(srcs, k, epsilon=eps, with_idx=with_idx)
+    for i, s in enumerate(srcs):
+        wid, wsc, wr, _ = oracle.twin_topk_query(g, int(s), k, eps, seed=SEED, index=index)
+        assert rounds[i] == wr
+        assert (ids[i] == wid).all()
+        assert (sc[i] == wsc).all()
+        # against the reference-order oracle: same top of the list, close scores
+        rid, rsc, rr, _ = oracle.topk_query(g, int(s), k, eps, seed=SEED, index=index)
+        exact = oracle.power_iteration(g, int(s))
+        if g.deg[s] > 0:
+            truth = set(np.argsort(-exact)[:k].tolist())
+            assert len(truth & set(ids[i].tolist())) >= int(0.8 * k)
+            assert len(set(rid.tolist()) & set(ids[i].tolist())) >= int(0.7 * k)
+            assert abs(sc[i][0] - rsc[0]) / rsc[0] < 0.1
+        else:
+            assert ids[i][0] == s and sc[i][0] == 1.0 and (sc[i][1:] == 0).all()
+    engine.clear_index()
+
+
+def test_topk_argument_checks(engine, oracle, tiny):
+    import fora_amd
+    g = tiny
+    _load(engine, g, epsilon=0.5, opt=True)
+    with pytest.raises(fora_amd.ForaError):
+        engine.topk(np.array([1], dtype=np.int32), g.n, epsilon=0.5)   # assert(k < n-1), query.h:1317
+    with pytest.raises(fora_amd.ForaError):
+        engine.topk(np.array([1], dtype=np.int32), 1, epsilon=0.5)     # assert(k > 1), query.h:1318
+    with pytest.raises(fora_amd.ForaError):
+        engine.topk(np.array([1], dtype=np.int32), 10, epsilon=0.5, with_idx=True)
