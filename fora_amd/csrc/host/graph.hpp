@@ -1,0 +1,126 @@
+// graph.hpp -- text graph loader of the `fora` command line.
+// Same inputs and semantics as the reference's Graph (graph.h:37-163): attribute.txt gives n
+// and m ("n=...", "m=..."), graph.txt is a "src dst" edge list; ids must be < n, self loops
+// are dropped, duplicates kept, per-node neighbour order is file order.  Storage is CSR
+// (row_ptr int64[n+1], col int32[nnz]) instead of vector<vector<int>>.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace forahost {
+
+struct Graph {
+    int32_t n = 0;
+    long long m = 0; // from attribute.txt, never recounted (graph.h:58-63)
+    std::vector<int64_t> row_ptr;
+    std::vector<int32_t> col;
+    std::string data_folder;
+    std::string error;
+
+    bool init_nm() { // graph.h:48-64
+        const std::string f = data_folder + "attribute.txt";
+        FILE *fp = fopen(f.c_str(), "r");
+        if (!fp) { error = "attribute file " + f + " not find"; return false; } // config.cpp:20-26
+        int c;
+        long long v;
+        while ((c = fgetc(fp)) != EOF && c != '=') {}
+        if (c == EOF || fscanf(fp, "%lld", &v) != 1) { fclose(fp); error = "bad attribute file"; return false; }
+        n = (int32_t)v;
+        while ((c = fgetc(fp)) != EOF && c != '=') {}
+        if (c == EOF || fscanf(fp, "%lld", &v) != 1) { fclose(fp); error = "bad attribute file"; return false; }
+        m = v;
+        fclose(fp);
+        return n > 0;
+    }
+
+    bool init_graph() { // graph.h:89-163, plain branch :151-161
+        if (!init_nm()) return false;
+        const std::string f = data_folder + "graph.txt";
+        FILE *fp = fopen(f.c_str(), "r");
+        if (!fp) { error = "graph file " + f + " not find"; return false; }
+        std::vector<int32_t> src, dst;
+        src.reserve((size_t)(m > 0 ? m : 0));
+        dst.reserve((size_t)(m > 0 ? m : 0));
+        int t1, t2;
+        while (fscanf(fp, "%d%d", &t1, &t2) == 2) {
+            if (t1 >= n || t2 >= n || t1 < 0 || t2 < 0) { // assert(t1 < n); assert(t2 < n);
+                fclose(fp);
+                error = "node id out of range in graph.txt";
+                return false;
+            }
+            if (t1 == t2) continue; // graph.h:157
+            src.push_back(t1);
+            dst.push_back(t2);
+        }
+        fclose(fp);
+        row_ptr.assign((size_t)n + 1, 0);
+        for (int32_t s : src) row_ptr[(size_t)s + 1]++;
+        for (int32_t v = 0; v < n; v++) row_ptr[(size_t)v + 1] += row_ptr[v];
+        col.resize(src.size());
+        std::vector<int64_t> cur(row_ptr.begin(), row_ptr.end() - 1);
+        for (size_t e = 0; e < src.size(); e++) col[(size_t)cur[src[e]]++] = dst[e];
+        return true;
+    }
+
+    bool load_ss_query(std::vector<int32_t> &queries) { // algo.h:511-522
+        const std::string f = data_folder + "ssquery.txt";
+        FILE *fp = fopen(f.c_str(), "r");
+        if (!fp) { error = "query file does not exist, please generate ss query files first"; return false; }
+        int v;
+        while (fscanf(fp, "%d", &v) == 1) queries.push_back(v);
+        fclose(fp);
+        return true;
+    }
+};
+
+// ---- walk index files ---------------------------------------------------------------
+// Names follow build.h:147-181.  The reference writes Boost binary_oarchive streams, which
+// cannot be produced or checked here (no Boost); this is a native container with the same
+// two arrays (rw_idx, rw_idx_info) -- interop with Boost files is SURVEY.md 8f rank 1.
+struct IndexFile {
+    static constexpr uint64_t MAGIC = 0x31584449414F46ull; // "FOAIDX1"
+    static std::string base(const std::string &loc, double rmax_scale, bool opt, const char *kind) {
+        std::string f = loc + "randwalks.";
+        if (rmax_scale != 1) f += std::to_string(rmax_scale) + ".";
+        f += kind;
+        if (opt) f += ".onehopopt";
+        return f;
+    }
+    static bool write(const std::string &loc, double rmax_scale, bool opt, int32_t n, const std::vector<int32_t> &rw,
+                      const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, std::string &err) {
+        FILE *a = fopen(base(loc, rmax_scale, opt, "idx").c_str(), "wb");
+        FILE *b = fopen(base(loc, rmax_scale, opt, "info").c_str(), "wb");
+        if (!a || !b) { err = "cannot write index files in " + loc; if (a) fclose(a); if (b) fclose(b); return false; }
+        uint64_t h[2] = {MAGIC, (uint64_t)rw.size()};
+        fwrite(h, 8, 2, a);
+        fwrite(rw.data(), 4, rw.size(), a);
+        uint64_t g[2] = {MAGIC, (uint64_t)n};
+        fwrite(g, 8, 2, b);
+        for (int32_t v = 0; v < n; v++) { uint64_t p[2] = {off[v], cnt[v]}; fwrite(p, 8, 2, b); } // pair<u64 off, ulong cnt>
+        fclose(a); fclose(b);
+        return true;
+    }
+    static bool read(const std::string &loc, double rmax_scale, bool opt, int32_t n, std::vector<int32_t> &rw,
+                     std::vector<uint64_t> &off, std::vector<uint64_t> &cnt, std::string &err) {
+        const std::string fa = base(loc, rmax_scale, opt, "idx"), fb = base(loc, rmax_scale, opt, "info");
+        FILE *a = fopen(fa.c_str(), "rb");
+        if (!a) { err = "index file " + fa + " not find"; return false; } // assert_file_exist, build.h:197
+        FILE *b = fopen(fb.c_str(), "rb");
+        if (!b) { fclose(a); err = "index file " + fb + " not find"; return false; }
+        uint64_t h[2], g[2];
+        bool ok = fread(h, 8, 2, a) == 2 && fread(g, 8, 2, b) == 2 && h[0] == MAGIC && g[0] == MAGIC && g[1] == (uint64_t)n;
+        if (ok) {
+            rw.resize(h[1]);
+            ok = fread(rw.data(), 4, rw.size(), a) == rw.size();
+            off.resize((size_t)n); cnt.resize((size_t)n);
+            for (int32_t v = 0; ok && v < n; v++) { uint64_t p[2]; ok = fread(p, 8, 2, b) == 2; off[v] = p[0]; cnt[v] = p[1]; }
+        }
+        fclose(a); fclose(b);
+        if (!ok) err = "index files are not in this build's format (Boost archives are not supported)";
+        return ok;
+    }
+};
+
+} // namespace forahost

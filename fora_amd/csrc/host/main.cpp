@@ -1,0 +1,320 @@
+// fora -- command line of the MI355X-native FORA engine: `fora query|topk|build ...`.
+// Drop-in for the reference's main (fora.cpp:56-292) on the FORA path: same actions, flag
+// names, input files and result JSON; the per-source loops of query() (query.h:1460-1481) and
+// topk() (query.h:1397-1401) become batched calls through the C ABI of libfora_hip.so.
+#include "config.hpp"
+#include "graph.hpp"
+#include "fora_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sys/resource.h>
+
+using namespace forahost;
+using std::cerr;
+using std::cout;
+using std::endl;
+using std::string;
+
+static Config config;
+static Result result;
+static Timers timers;
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static double proc_memory_mb() { // get_proc_memory()/1000.0, mylib.h:695-699
+    struct rusage u;
+    getrusage(RUSAGE_SELF, &u);
+    return u.ru_maxrss / 1000.0;
+}
+static void split_line() { cout << "-----------------------------------------------" << endl; }
+
+static const char *HELP =
+    "fora query --algo <algo> [options]\n"
+    "fora topk  --algo <algo> [options]\n"
+    "fora build [options]\n"
+    "fora generate-ss-query [options]\n"
+    "fora\n"
+    "\n"
+    "algo: \n"
+    "  fora\n"
+    "options: \n"
+    "  --prefix <prefix>\n"
+    "  --epsilon <epsilon>\n"
+    "  --dataset <dataset>\n"
+    "  --query_size <queries count>\n"
+    "  --k <top k>\n"
+    "  --with_idx\n"
+    "  --opt\n"
+    "  --result_dir <directory to place results>\n"
+    "  --rmax_scale <scale of rmax>\n"
+    "  --seed <walk RNG seed>   (MI355X build: Philox, reproducible)\n"
+    "  --device <gpu ordinal>   --batch <queries in flight>\n";
+
+#define FAIL(ctx, what)                                                                        \
+    do {                                                                                       \
+        cerr << what << ": " << (ctx ? fora_hip_last_error(ctx) : "no context") << endl;      \
+        return 1;                                                                              \
+    } while (0)
+
+// display_time_usage (algo.h:368-402) + set_result (algo.h:404-440)
+static void finish(const Graph &graph, int used_counter, unsigned query_size, double n_walks, double n_hit) {
+    const double tot = timers.get(used_counter);
+    cout << "Total cost (s): " << tot << endl;
+    cout << timers.get(RONDOM_WALK) * 100.0 / tot << "%" << " for random walk cost" << endl;
+    cout << timers.get(FWD_LU) * 100.0 / tot << "%" << " for forward push cost" << endl;
+    split_line();
+    if (config.with_rw_idx) cout << "Average rand-walk idx hit ratio: " << n_hit * 100.0 / n_walks << "%" << endl;
+    cout << "Average query time (s):" << tot / query_size << endl;
+    cout << "Memory usage (MB):" << proc_memory_mb() << endl << endl;
+    config.query_size = query_size;
+    result.m = graph.m; result.n = graph.n;
+    result.avg_query_time = tot / query_size;
+    result.total_mem_usage = proc_memory_mb();
+    result.total_time_usage = tot;
+    result.num_randwalk = n_walks;
+    if (config.with_rw_idx) { result.num_rw_idx_use = n_hit; result.hit_idx_ratio = n_hit / n_walks; }
+    result.randwalk_time = timers.get(RONDOM_WALK);
+    result.randwalk_time_ratio = timers.get(RONDOM_WALK) * 100 / tot;
+    result.propagation_time = timers.get(FWD_LU);
+    result.propagation_time_ratio = timers.get(FWD_LU) * 100 / tot;
+    if (config.action == TOPK) result.topk_sort_time = timers.get(SORT_MAP);
+}
+
+static int open_engine(const Graph &graph, fora_ctx **ctx) {
+    int rc = fora_hip_create(config.device, ctx);
+    if (rc) { cerr << "no usable MI355X (gfx950) device: fora_hip_create rc=" << rc << endl; return 1; }
+    if (fora_hip_set_graph(*ctx, graph.n, graph.m, graph.row_ptr.data(), graph.col.data())) FAIL(*ctx, "set_graph");
+    if (fora_hip_set_params(*ctx, config.alpha, config.epsilon, config.rmax_scale, config.opt, config.seed)) FAIL(*ctx, "set_params");
+    fora_hip_get_params(*ctx, &config.rmax, &config.omega); // fora_setting, algo.h:455-463
+    if (config.batch) fora_hip_set_batch(*ctx, config.batch);
+    return 0;
+}
+
+static int load_index(fora_ctx *ctx, const Graph &graph) { // deserialize_idx, build.h:194-207
+    std::vector<int32_t> rw;
+    std::vector<uint64_t> off, cnt;
+    string err;
+    if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)) {
+        cerr << err << endl;
+        return 1;
+    }
+    if (fora_hip_set_index(ctx, rw.data(), rw.size(), off.data(), cnt.data())) FAIL(ctx, "set_index");
+    return 0;
+}
+
+static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
+    info("config.algo", config.algo);
+    std::vector<int32_t> queries;
+    if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); } // algo.h:513-516
+    unsigned query_size = std::min<unsigned>((unsigned)queries.size(), config.query_size);
+    info("query_size", query_size);
+    if (!(config.rmax_scale >= 0)) { cerr << "rmax_scale must be >= 0" << endl; return 1; } // query.h:1424
+    fora_ctx *ctx = nullptr;
+    if (open_engine(graph, &ctx)) return 1;
+    info("config.rmax", config.rmax);
+    info("config.omega", config.omega);
+    if (config.with_rw_idx && load_index(ctx, graph)) { fora_hip_destroy(ctx); return 1; }
+    std::vector<fora_query_stats> st(query_size);
+    fora_hip_reset_timing(ctx);
+    const double t0 = now_s();
+    if (fora_hip_query_batch(ctx, queries.data(), (int)query_size, config.with_rw_idx, nullptr, st.data())) FAIL(ctx, "query");
+    const double dt = now_s() - t0;
+    fora_timing tm;
+    fora_hip_get_timing(ctx, &tm);
+    double n_walks = 0, n_hit = 0, total_rsum = 0;
+    for (unsigned i = 0; i < query_size; i++) {
+        cout << i + 1 << ". source node:" << queries[i] << endl; // query.h:1473
+        n_walks += (double)st[i].n_walks;
+        n_hit += (double)st[i].n_idx_hit;
+        total_rsum += st[i].rsum * (1 - config.alpha); // query.h:896,899
+    }
+    split_line();
+    info("avg_rsum*config.omega", total_rsum / query_size * config.omega);
+    timers.add(FORA_QUERY, dt);
+    timers.add(FWD_LU, (tm.push_pop_ms + tm.push_expand_ms) * 1e-3);
+    timers.add(RONDOM_WALK, (tm.walk_alloc_ms + tm.walk_ms) * 1e-3);
+    finish(graph, FORA_QUERY, query_size, n_walks, n_hit);
+    fora_hip_destroy(ctx);
+    return 0;
+}
+
+static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with --opt
+    std::vector<int32_t> queries;
+    if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); }
+    info("queries.size()", queries.size());
+    unsigned query_size = std::min<unsigned>((unsigned)queries.size(), config.query_size);
+    if (!(config.k < (unsigned)graph.n - 1) || !(config.k > 1)) { cerr << "k out of range" << endl; return 1; } // :1317-1318
+    info("config.k", config.k);
+    split_line();
+    if (!config.opt) { // fora_query_topk_with_bound (query.h:909-969) is SURVEY.md 8f rank 2
+        cerr << "topk without --opt (bounds variant) is not part of this build; pass --opt" << endl;
+        return 1;
+    }
+    fora_ctx *ctx = nullptr;
+    if (open_engine(graph, &ctx)) return 1;
+    if (config.with_rw_idx && load_index(ctx, graph)) { fora_hip_destroy(ctx); return 1; }
+    std::vector<int32_t> ids((size_t)query_size * config.k), rounds(query_size);
+    std::vector<double> scores((size_t)query_size * config.k);
+    fora_hip_reset_timing(ctx);
+    const double t0 = now_s();
+    if (fora_hip_topk_batch(ctx, queries.data(), (int)query_size, (int)config.k, config.epsilon, config.rmax_scale,
+                            config.with_rw_idx, ids.data(), scores.data(), rounds.data()))
+        FAIL(ctx, "topk");
+    const double dt = now_s() - t0;
+    fora_timing tm;
+    fora_hip_get_timing(ctx, &tm);
+    long num_iter_topk = 0;
+    const string out = config.exe_result_dir + config.graph_alias + ".topk.k-" + std::to_string(config.k) + ".txt";
+    FILE *fo = fopen(out.c_str(), "w");
+    for (unsigned i = 0; i < query_size; i++) {
+        cout << i + 1 << ". source node:" << queries[i] << endl; // query.h:1398
+        num_iter_topk += rounds[i];
+        if (fo) {
+            fprintf(fo, "%d", queries[i]);
+            for (unsigned j = 0; j < config.k; j++) fprintf(fo, " %d:%.17g", ids[(size_t)i * config.k + j], scores[(size_t)i * config.k + j]);
+            fprintf(fo, "\n");
+        }
+    }
+    if (fo) fclose(fo);
+    split_line();
+    cout << "average iter times:" << num_iter_topk / query_size << endl; // query.h:1403
+    timers.add(0, dt);
+    timers.add(FWD_LU, (tm.push_pop_ms + tm.push_expand_ms) * 1e-3);
+    timers.add(RONDOM_WALK, (tm.walk_alloc_ms + tm.walk_ms) * 1e-3);
+    timers.add(SORT_MAP, tm.other_ms * 1e-3);
+    timers.add(FORA_QUERY, dt);
+    finish(graph, FORA_QUERY, query_size, (double)tm.walks, 0);
+    cout << "top-k lists written to " << out << endl;
+    fora_hip_destroy(ctx);
+    return 0;
+}
+
+static int do_build(Graph &graph) { // build(), build.h:302-366
+    fora_ctx *ctx = nullptr;
+    if (open_engine(graph, &ctx)) return 1;
+    uint64_t total = 0;
+    if (fora_hip_index_sizes(ctx, &total, nullptr, nullptr)) FAIL(ctx, "index_sizes");
+    info("tuned_index_size", total);
+    puts("rand-walking...");
+    info("config.rmax", config.rmax);
+    info("config.omega", config.omega);
+    info("config.rmax*config.omega", config.rmax * config.omega);
+    double t0 = now_s();
+    if (fora_hip_build_index(ctx)) FAIL(ctx, "build_index");
+    timers.add(1, now_s() - t0);
+    puts("materializing...");
+    t0 = now_s();
+    std::vector<int32_t> rw(std::max<uint64_t>(1, total));
+    std::vector<uint64_t> off((size_t)graph.n), cnt((size_t)graph.n);
+    if (fora_hip_get_index(ctx, rw.data(), total, off.data(), cnt.data())) FAIL(ctx, "get_index");
+    rw.resize(total);
+    info("rw_idx.size()", rw.size());
+    string err;
+    if (!IndexFile::write(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)) {
+        cerr << err << endl;
+        fora_hip_destroy(ctx);
+        return 1;
+    }
+    timers.add(2, now_s() - t0);
+    cout << "Memory usage (MB):" << proc_memory_mb() << endl << endl;
+    fora_hip_destroy(ctx);
+    return 0;
+}
+
+int main(int argc, char *argv[]) {
+    const string start_time = now_str();
+    for (int i = 0; i < argc; i++)
+        if (string(argv[i]) == "--help") { cout << HELP << endl; return 0; } // fora.cpp:93-96
+    if (argc < 2) { cerr << "sub command not regoznized" << endl; return 1; }
+    config.action = argv[1]; // fora.cpp:98
+    cout << "action: " << config.action << endl;
+    for (int i = 0; i < argc; i++) { // fora.cpp:111-160
+        const string arg = argv[i];
+        auto next = [&](const char *what) -> const char * {
+            if (i + 1 >= argc) { cerr << "missing value for " << what << endl; exit(1); }
+            return argv[i + 1];
+        };
+        if (arg == "--algo") config.algo = next("--algo");
+        else if (arg == "--epsilon") { config.epsilon = atof(next("--epsilon")); info("config.epsilon", config.epsilon); }
+        else if (arg == "--multithread") config.multithread = true;
+        else if (arg == "--result_dir") config.exe_result_dir = next("--result_dir");
+        else if (arg == "--exact_ppr_path") config.exact_pprs_folder = next("--exact_ppr_path");
+        else if (arg == "--with_idx") config.with_rw_idx = true;
+        else if (arg == "--rmax_scale") config.rmax_scale = atof(next("--rmax_scale"));
+        else if (arg == "--force-rebuild") config.force_rebuild = true;
+        else if (arg == "--query_size") config.query_size = (unsigned)atoi(next("--query_size"));
+        else if (arg == "--hub_space") config.hub_space_consum = (unsigned)atoi(next("--hub_space"));
+        else if (arg == "--version") config.version = next("--version");
+        else if (arg == "--k") config.k = (unsigned)atoi(next("--k"));
+        else if (arg == "--rw_ratio") config.rw_cost_ratio = atof(next("--rw_ratio"));
+        else if (arg == "--prefix") config.prefix = next("--prefix");
+        else if (arg == "--dataset") config.graph_alias = next("--dataset");
+        else if (arg == "--opt") config.opt = true;
+        else if (arg == "--balanced") config.balanced = true;
+        else if (arg == "--seed") config.seed = strtoull(next("--seed"), nullptr, 0);
+        else if (arg == "--device") config.device = atoi(next("--device"));
+        else if (arg == "--batch") config.batch = atoi(next("--batch"));
+        else if (arg.substr(0, 2) == "--") { cerr << "command not recognize " << arg << endl; return 1; } // fora.cpp:156-159
+    }
+    info("config.version", config.version);
+    info("config.action", config.action);
+    if (config.balanced) { cerr << "--balanced (wall-clock driven rmax, query.h:848-884) is not supported" << endl; return 1; }
+
+    const string act = config.action;
+    if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH) {
+        cerr << "sub command not regoznized" << endl; // fora.cpp:278-281
+        return 1;
+    }
+    if ((act == QUERY || act == TOPK) && config.algo != FORA) { // fora.cpp:169-175
+        info("Wrong algo param: ", config.algo);
+        cerr << "only --algo fora is part of this build" << endl;
+        return 1;
+    }
+    if ((act == QUERY || act == TOPK || act == BUILD) && !(config.epsilon > 0)) { cerr << "--epsilon must be > 0" << endl; return 1; }
+    config.graph_location = config.get_graph_folder();
+    Graph graph;
+    graph.data_folder = config.graph_location;
+    const bool ok = act == GEN_SS_QUERY ? graph.init_nm() : graph.init_graph(); // graph.h:40-43
+    if (!ok) { cerr << graph.error << endl; return 1; }
+    cout << "init graph n: " << graph.n << " m: " << graph.m << endl;
+    config.delta = 1.0 / graph.n; // init_parameter, graph.h:173-183
+    config.pfail = 1.0 / graph.n;
+    config.dbar = double(graph.m) / double(graph.n);
+    info("graph.n", graph.n);
+    info("graph.m", graph.m);
+
+    int rc = 0;
+    if (act == CHECK_GRAPH) {
+        uint64_t h = 1469598103934665603ull;
+        for (int32_t c : graph.col) { h ^= (uint32_t)c; h *= 1099511628211ull; }
+        for (int64_t r : graph.row_ptr) { h ^= (uint64_t)r; h *= 1099511628211ull; }
+        cout << "nnz: " << graph.col.size() << " csr_fnv1a: " << h << endl;
+        return 0;
+    } else if (act == GEN_SS_QUERY) { // algo.h:498-509, seeded instead of rand()
+        const string f = config.graph_location + "ssquery.txt";
+        if (FILE *t = fopen(f.c_str(), "r")) { fclose(t); puts("ss query set exists"); return 0; }
+        std::ofstream qf(f);
+        uint64_t s = config.seed ? config.seed : 1;
+        for (unsigned i = 0; i < config.query_size; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            qf << (int)(s % (uint64_t)graph.n) << "\n";
+        }
+        return 0;
+    } else if (act == QUERY) rc = do_query(graph);
+    else if (act == TOPK) rc = do_topk(graph);
+    else if (act == BUILD) { const double t0 = now_s(); rc = do_build(graph); timers.add(0, now_s() - t0); }
+    if (rc) return rc;
+    timers.show(); // fora.cpp:282
+    if (act == QUERY || act == TOPK) { // fora.cpp:283-287
+        string cmd;
+        for (int i = 1; i < argc; i++) cmd += string(" ") + argv[i];
+        const string p = save_json(config, result, timers, start_time, cmd);
+        cout << "result written to " << p << endl;
+    }
+    return 0;
+}

@@ -1,0 +1,136 @@
+"""`fora` command line (fora_amd/bin/fora): flag handling and loader on CPU; build / query /
+topk end to end on the GPU.  Mirrors fora.cpp:56-292 behaviour on the FORA path."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FORA = os.path.join(ROOT, "fora_amd", "bin", "fora")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import __graft_entry__
+    __graft_entry__.build()
+    assert os.path.exists(FORA)
+    return FORA
+
+
+def _write_dataset(folder, g, queries):
+    os.makedirs(folder, exist_ok=True)
+    with open(os.path.join(folder, "attribute.txt"), "w") as f:
+        f.write(f"n={g.n}\nm={g.m}\n")
+    src = np.repeat(np.arange(g.n), np.diff(g.row_ptr))
+    with open(os.path.join(folder, "graph.txt"), "w") as f:
+        for s, d in zip(src.tolist(), g.col.tolist()):
+            f.write(f"{s} {d}\n")
+        f.write("7 7\n")  # a self loop the loader must drop (graph.h:157)
+    with open(os.path.join(folder, "ssquery.txt"), "w") as f:
+        for q in queries:
+            f.write(f"{int(q)}\n")
+
+
+def _run(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_help_and_bad_flags(cli):
+    r = _run([cli, "--help"])
+    assert r.returncode == 0 and "fora query --algo <algo> [options]" in r.stdout
+    r = _run([cli, "query", "--algo", "fora", "--nonsense"])
+    assert r.returncode == 1 and "command not recognize --nonsense" in r.stderr   # fora.cpp:156-159
+    r = _run([cli, "frobnicate"])
+    assert r.returncode == 1 and "sub command not regoznized" in r.stderr         # fora.cpp:278-281
+    r = _run([cli, "query", "--algo", "bippr", "--epsilon", "0.5"])
+    assert r.returncode == 1
+
+
+def test_loader_matches_oracle(cli, oracle, tiny, tmp_path):
+    folder = tmp_path / "data" / "toy"
+    _write_dataset(str(folder), tiny, [1, 2, 3])
+    r = _run([cli, "check-graph", "--prefix", str(tmp_path / "data") + "/", "--dataset", "toy"])
+    assert r.returncode == 0, r.stderr
+    assert f"init graph n: {tiny.n} m: {tiny.m}" in r.stdout
+    g2 = oracle.Graph.from_folder(str(folder))
+    assert (g2.row_ptr == tiny.row_ptr).all() and (g2.col == tiny.col).all()
+    h = 1469598103934665603
+    mask = (1 << 64) - 1
+    for c in g2.col.tolist():
+        h = ((h ^ (c & 0xFFFFFFFF)) * 1099511628211) & mask
+    for p in g2.row_ptr.tolist():
+        h = ((h ^ p) * 1099511628211) & mask
+    assert f"nnz: {g2.col.size} csr_fnv1a: {h}" in r.stdout
+    # missing graph file -> error exit like assert_file_exist (config.cpp:20-26)
+    r = _run([cli, "check-graph", "--prefix", str(tmp_path / "data") + "/", "--dataset", "nope"])
+    assert r.returncode == 1 and "not find" in r.stderr
+    # id >= n -> assert in graph.h:155
+    with open(folder / "graph.txt", "a") as f:
+        f.write(f"0 {tiny.n}\n")
+    r = _run([cli, "check-graph", "--prefix", str(tmp_path / "data") + "/", "--dataset", "toy"])
+    assert r.returncode == 1
+
+
+def test_query_without_gpu_fails_loudly(cli, tiny, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    folder = tmp_path / "data" / "toy"
+    _write_dataset(str(folder), tiny, [1, 2, 3])
+    r = _run([cli, "query", "--algo", "fora", "--prefix", str(tmp_path / "data") + "/", "--dataset", "toy",
+              "--epsilon", "0.5"])
+    assert r.returncode != 0 and "no usable MI355X" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
+    from conftest import pick_sources
+    g = small
+    queries = pick_sources(g, 12, 41)
+    folder = tmp_path / "data" / "g32k"
+    _write_dataset(str(folder), g, queries)
+    common = ["--prefix", str(tmp_path / "data") + "/", "--dataset", "g32k", "--epsilon", "0.5",
+              "--result_dir", str(tmp_path / "res")]
+    r = _run([cli, "build", *common])
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(folder / "randwalks.idx") and os.path.exists(folder / "randwalks.info")  # build.h:147-181
+    rmax, omega = oracle.fora_setting(g.n, g.m, 0.5)
+    total, _, _ = oracle.index_sizes(g, rmax, omega)
+    assert f"tuned_index_size={total}" in r.stdout
+    for extra in ([], ["--with_idx"]):
+        r = _run([cli, "query", "--algo", "fora", "--query_size", "10", *common, *extra])
+        assert r.returncode == 0, r.stderr
+        assert "1. source node:%d" % queries[0] in r.stdout and "10. source node:%d" % queries[9] in r.stdout
+        assert "11. source node" not in r.stdout                      # min(file, --query_size), query.h:1419
+        assert "Total cost (s):" in r.stdout and "% for forward push cost" in r.stdout
+        assert "Average query time (s):" in r.stdout and "Memory usage (MB):" in r.stdout
+        if extra:
+            assert "Average rand-walk idx hit ratio: 100%" in r.stdout
+        name = "g32k.query.fora.%s.k-500.rmax-1.000000.json" % ("with_idx" if extra else "without_idx")
+        j = json.load(open(tmp_path / "res" / "execution" / name))     # config.h:257-279
+        assert j["config"]["algo"] == "fora" and j["config"]["query-size"] == "10"
+        assert float(j["config"]["rmax"]) == rmax and float(j["config"]["omega"]) == omega
+        assert int(j["result"]["n"]) == g.n and int(j["result"]["m"]) == g.m
+        walks = sum(oracle.twin_query(g, int(s), rmax, omega, seed=0x464F5241)[2]["n_walks"] for s in queries[:10])
+        assert float(j["result"]["total number of rand-walks"]) == walks
+        assert set(j["timer"]) >= {"3", "5", "6"}
+    # build --opt + topk --opt --with_idx
+    r = _run([cli, "build", "--opt", *common])
+    assert r.returncode == 0 and os.path.exists(folder / "randwalks.idx.onehopopt")
+    r = _run([cli, "topk", "--algo", "fora", "--opt", "--with_idx", "--k", "20", "--query_size", "5", *common])
+    assert r.returncode == 0, r.stderr
+    assert "average iter times:" in r.stdout
+    lines = open(tmp_path / "res" / "g32k.topk.k-20.txt").read().strip().split("\n")
+    assert len(lines) == 5
+    rmax_o, omega_o = oracle.fora_setting(g.n, g.m, 0.5, opt=True)
+    index = oracle.build_index(g, 0x464F5241, rmax_o, omega_o, opt=True)
+    ids, sc, _, _ = oracle.twin_topk_query(g, int(queries[0]), 20, 0.5, seed=0x464F5241, index=index)
+    got = lines[0].split()
+    assert int(got[0]) == queries[0]
+    assert [int(x.split(":")[0]) for x in got[1:]] == ids.tolist()
+    assert [float(x.split(":")[1]) for x in got[1:]] == sc.tolist()
+    # topk without --opt is the bounds variant: refused, not silently substituted
+    r = _run([cli, "topk", "--algo", "fora", "--k", "20", *common])
+    assert r.returncode == 1

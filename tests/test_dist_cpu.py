@@ -1,0 +1,66 @@
+"""Multi-rank path on CPU: world_size-2 gloo run of the sharding + top-k gather used by
+bench.py / multi-GPU drivers.  The per-rank compute is the oracle twin here
+(no GPU in this container); on a node each rank runs the HIP engine instead."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+from fora_amd import synth
+from fora_amd.dist import env_world, shard_sources, gather_topk, max_over_ranks, sum_over_ranks
+import oracle_lib as O
+rank, local_rank, world = env_world()
+dist.init_process_group("gloo")
+n, m, seed = synth.PRESETS["tiny"]
+src, dst = synth.rmat_graph(n, m, seed)
+g = O.Graph.from_edges(n, m, src, dst)
+sources = synth.query_set(n, 7, 99)          # 7 queries over 2 ranks: ragged shards (4 + 3)
+mine = shard_sources(sources, rank, world)
+k = 8
+ids = np.zeros((len(mine), k), dtype=np.int32); sc = np.zeros((len(mine), k))
+for i, s in enumerate(mine):
+    ids[i], sc[i], _, _ = O.twin_topk_query(g, int(s), k, 0.5, seed=5)
+dist.barrier()
+all_ids, all_sc = gather_topk(ids, sc, len(sources), rank, world)
+t = max_over_ranks(1.0 + rank, world)
+tot = sum_over_ranks([len(mine)], world)
+if rank == 0:
+    ok = True
+    for qi, s in enumerate(sources):
+        wi, ws, _, _ = O.twin_topk_query(g, int(s), k, 0.5, seed=5)
+        ok &= bool((all_ids[qi] == wi).all() and (all_sc[qi] == ws).all())
+    print("RESULT", ok, t, tot[0])
+dist.destroy_process_group()
+'''
+
+
+def test_world2_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert line[1] == "True" and float(line[2]) == 2.0 and float(line[3]) == 7.0
+
+
+def test_shard_layout():
+    from fora_amd.dist import shard_sources, unshard_index
+    src = np.arange(10)
+    parts = [shard_sources(src, r, 4) for r in range(4)]
+    assert [p.tolist() for p in parts] == [[0, 4, 8], [1, 5, 9], [2, 6], [3, 7]]
+    per = 3
+    flat = np.full(4 * per, -1)
+    for r, p in enumerate(parts):
+        flat[r * per:r * per + len(p)] = p
+    assert flat[unshard_index(10, 4)].tolist() == list(range(10))
