@@ -169,6 +169,8 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     fora_timing tm;
     fora_hip_get_timing(ctx, &tm);
     long num_iter_topk = 0;
+    if (config.exe_result_dir.empty() || config.exe_result_dir.back() != '/') config.exe_result_dir += "/";
+    make_dirs(config.exe_result_dir);
     const string out = config.exe_result_dir + config.graph_alias + ".topk.k-" + std::to_string(config.k) + ".txt";
     FILE *fo = fopen(out.c_str(), "w");
     for (unsigned i = 0; i < query_size; i++) {
