@@ -61,6 +61,16 @@ struct fora_ctx {
     QState *d_qs = nullptr;
     int32_t *d_src = nullptr;
     uint32_t *d_err = nullptr;
+    // bucketed push (n <= MAX_BINS * BIN_SIZE)
+    bool binned = false;
+    int nbins = 0;
+    uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
+    PushSegQ *d_segq = nullptr;
+    uint32_t *d_segq_count = nullptr, *d_bk_w = nullptr, *d_bk_count = nullptr;
+    uint64_t *d_bk_inc = nullptr;
+    uint64_t segq_cap = 0;
+    uint32_t bk_cap = 0;
+    uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
     uint8_t *d_active = nullptr;
     unsigned long long *d_above = nullptr;
@@ -111,6 +121,10 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     c->topk_cap = 0;
+    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_segq); dfree(c->d_segq_count);
+    dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count);
+    if (c->h_flc) (void)hipHostFree(c->h_flc);
+    c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     c->h_pinned = nullptr;
     c->B = 0;
@@ -118,42 +132,75 @@ void free_workspace(fora_ctx *c) {
 
 constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
 
-// bytes of workspace one slot needs
-uint64_t slot_bytes(const fora_ctx *c, double omega_hint) {
+constexpr int SPEC = 3;          // levels launched ahead of the frontier-size readback
+constexpr int FLC_RING = SPEC + 2;
+
+static bool want_binned(const fora_ctx *c) {
+    const char *e = getenv("FORA_HIP_DIRECT");
+    if (e && e[0] == '1') return false;
+    return (uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE;
+}
+static uint32_t want_bk_cap() {
+    const char *e = getenv("FORA_HIP_BKCAP");
+    if (e && atoi(e) > 0) return (uint32_t)atoi(e);
+    return 65536;
+}
+
+struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
+static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
+    WsPlan p{};
     const uint64_t n = (uint64_t)c->n;
-    const uint64_t segs = n + (uint64_t)c->nnz / PUSH_SEG + 64;
+    p.binned = want_binned(c);
+    p.segs = n + (uint64_t)c->nnz / PUSH_SEG + 64; // per slot
     double walks = omega_hint > 0 ? omega_hint : 0;
     if (walks > 4e12) walks = 4e12;
-    const uint64_t wits = n + (uint64_t)(walks / WALK_SEG) + 64;
-    const uint64_t scratch = std::max(segs * sizeof(PushSeg), wits * sizeof(WalkItem));
-    return n * 8 * 4 + scratch;
+    p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
+    if (p.binned) {
+        p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
+        p.bk_cap = want_bk_cap();
+        p.segq_cap = p.segs;
+        p.scratch = p.wits * sizeof(WalkItem);
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * sizeof(PushSegQ) + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
+    } else {
+        p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
+        p.per_slot = n * 8 * 4 + p.scratch;
+    }
+    return p;
 }
 
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    const WsPlan p = plan_workspace(c, omega_hint);
     int B = c->batch_req > 0 ? c->batch_req : 0;
-    const uint64_t per = slot_bytes(c, omega_hint);
     if (B == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         uint64_t budget = (uint64_t)(fr * 0.6);
-        B = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, budget / per));
+        B = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, budget / p.per_slot));
     }
     B = std::max(1, B);
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
     const uint64_t n = (uint64_t)c->n;
-    const uint64_t segs = (uint64_t)B * (n + (uint64_t)c->nnz / PUSH_SEG + 64);
-    double walks = omega_hint > 0 ? omega_hint : 0;
-    if (walks > 4e12) walks = 4e12;
-    const uint64_t wits = (uint64_t)B * (n + (uint64_t)(walks / WALK_SEG) + 64);
-    if (c->B >= B && c->seg_cap >= segs && c->wit_cap >= wits) return FORA_OK;
+    const uint64_t scratch = (uint64_t)B * p.scratch;
+    if (c->B >= B && c->binned == p.binned && c->seg_cap * sizeof(PushSeg) >= scratch && c->bk_cap == p.bk_cap) return FORA_OK;
     free_workspace(c);
     const uint64_t slab = (uint64_t)B * n;
     HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
     HIPCHK(c, hipMalloc(&c->d_ppr, slab * 8));
-    HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
-    HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
-    const uint64_t scratch = std::max(segs * sizeof(PushSeg), wits * sizeof(WalkItem));
+    if (p.binned) {
+        HIPCHK(c, hipMalloc(&c->d_fl[0], slab * 4));
+        HIPCHK(c, hipMalloc(&c->d_fl[1], slab * 4));
+        HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
+        HIPCHK(c, hipMalloc(&c->d_segq, (uint64_t)B * p.segq_cap * sizeof(PushSegQ)));
+        HIPCHK(c, hipMalloc(&c->d_segq_count, (size_t)B * 4 * CSTRIDE));
+        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.nbins * p.bk_cap * 4));
+        HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.nbins * p.bk_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.nbins * 4 * CSTRIDE));
+        HIPCHK(c, hipHostMalloc(&c->h_flc, (size_t)FLC_RING * B * 4 * CSTRIDE));
+    } else {
+        HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
+    }
     HIPCHK(c, hipMalloc(&c->d_scratch, scratch));
     HIPCHK(c, hipMalloc(&c->d_counters, N_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_qs, (size_t)B * sizeof(QState)));
@@ -161,6 +208,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipMalloc(&c->d_err, sizeof(uint32_t)));
     HIPCHK(c, hipHostMalloc(&c->h_pinned, (MAX_LEVELS + 2) * sizeof(unsigned long long)));
     c->B = B;
+    c->binned = p.binned; c->nbins = p.nbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
     c->wl_cap = slab;
     c->seg_cap = scratch / sizeof(PushSeg);
     c->wit_cap = scratch / sizeof(WalkItem);
@@ -189,6 +237,11 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.alpha32 = (uint32_t)(c->alpha * 4294967296.0);
     d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
     d.alpha = c->alpha; d.omega = omega; d.opt = c->opt;
+    d.binned = c->binned ? 1 : 0; d.nbins = c->nbins;
+    d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
+    d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
+    d.segq = c->d_segq; d.segq_count = c->d_segq_count; d.segq_cap = c->segq_cap;
+    d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;
 }
@@ -220,6 +273,7 @@ void ev_collect(fora_ctx *c) { // call after the stream is idle
         case 3: c->timing.walk_ms += ms; c->timing.walk_launches++; break;
         case 4: c->timing.other_ms += ms; break;
         case 5: c->timing.batch_ms += ms; c->timing.batches++; break;
+        case 6: c->timing.push_accum_ms += ms; c->timing.push_accum_launches++; break;
         }
     }
     c->ev_used = 0;
@@ -237,31 +291,55 @@ int check_dev_err(fora_ctx *c) {
     return FORA_OK;
 }
 
-// Level loop of the push for the slots already initialised (frontier of level 0 in wl[0],
-// its size in wl_count[0]).  Launches run ahead of the host by SPEC levels: an empty
-// level costs two near-empty launches, a host round trip per level would cost more.
+// Level loop of the push for the slots already initialised (level-0 frontier in place).
+// Launches run ahead of the host by SPEC levels: an empty level costs a few near-empty
+// launches, a host round trip per level would cost more.
 int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
-    constexpr int SPEC = 3;
     hipEvent_t done[SPEC + 1];
     for (auto &e : done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int rc = FORA_OK;
     int L = 0;
+    const int nq = d.nq;
+    const unsigned xp = (unsigned)std::min(256, std::max(4, 2048 / std::max(1, nq)));
+    const unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
     for (;; L++) {
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
-        int h = ev_begin(c, 0);
-        hipLaunchKernelGGL(k_push_pop, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
-        ev_end(c, h);
-        h = ev_begin(c, 1);
-        hipLaunchKernelGGL(k_push_expand, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
-        ev_end(c, h);
+        if (c->binned) {
+            int h = ev_begin(c, 0);
+            hipLaunchKernelGGL(k_pushq_pop, dim3(xp, nq), dim3(BLOCK), 0, c->stream, d, L);
+            ev_end(c, h);
+            h = ev_begin(c, 1);
+            hipLaunchKernelGGL(k_pushq_bin, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
+            ev_end(c, h);
+            h = ev_begin(c, 6);
+            hipLaunchKernelGGL(k_pushq_accum, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
+            ev_end(c, h);
+            (void)hipMemcpyAsync(c->h_flc + (size_t)((L + 1) % FLC_RING) * c->B * CSTRIDE, d.fl_count[(L + 1) & 1],
+                                 (size_t)nq * 4 * CSTRIDE, hipMemcpyDeviceToHost, c->stream);
+        } else {
+            int h = ev_begin(c, 0);
+            hipLaunchKernelGGL(k_push_pop, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
+            ev_end(c, h);
+            h = ev_begin(c, 1);
+            hipLaunchKernelGGL(k_push_expand, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, L);
+            ev_end(c, h);
+            (void)hipMemcpyAsync(&c->h_pinned[L + 1], &d.wl_count[L + 1], sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, c->stream);
+        }
         c->timing.levels++;
-        (void)hipMemcpyAsync(&c->h_pinned[L + 1], &d.wl_count[L + 1], sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost, c->stream);
         (void)hipEventRecord(done[L % (SPEC + 1)], c->stream);
         if (L >= SPEC) {
             const int K = L - SPEC;
             if (hipEventSynchronize(done[K % (SPEC + 1)]) != hipSuccess) { rc = fail(c, FORA_E_HIP, "event sync"); break; }
-            if (c->h_pinned[K + 1] == 0) break;
+            bool empty;
+            if (c->binned) {
+                empty = true;
+                const uint32_t *cnt = c->h_flc + (size_t)((K + 1) % FLC_RING) * c->B * CSTRIDE;
+                for (int i = 0; i < nq && empty; i++) empty = cnt[(size_t)i * CSTRIDE] == 0;
+            } else {
+                empty = c->h_pinned[K + 1] == 0;
+            }
+            if (empty) break;
         }
     }
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -275,6 +353,15 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     return rc;
 }
 
+// per-level bookkeeping of the bucketed push that must start from zero
+int reset_binned_counters(fora_ctx *c) {
+    if (!c->binned) return FORA_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_fl_count, 0, (size_t)c->B * 2 * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_segq_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->nbins * 4 * CSTRIDE, c->stream));
+    return FORA_OK;
+}
+
 int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
     const uint64_t bytes = (uint64_t)nq * c->n * 8;
     int h = ev_begin(c, 4);
@@ -283,8 +370,9 @@ int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_src, sources, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    int rc = reset_binned_counters(c);
     ev_end(c, h);
-    return FORA_OK;
+    return rc;
 }
 
 enum { RUN_PUSH_ONLY = 1 };
@@ -740,6 +828,8 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             HIPCHK(c, hipMemcpyAsync(c->d_active, active.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_above, 0, (size_t)nb * 8, c->stream));
+            rc = reset_binned_counters(c);
+            if (rc) return rc;
             d = make_dev(c, nb, with_idx != 0, rmax, omega);
             int h = ev_begin(c, 4);
             hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, d, (const uint8_t *)c->d_active);

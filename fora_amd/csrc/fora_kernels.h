@@ -21,9 +21,24 @@ constexpr uint32_t WALK_SEG = 1024; // max walks per walk work item
 constexpr uint64_t FIX_ONE = 1ull << 62;
 constexpr uint32_t DEG_SAT = 0xFFFFFFu; // rowinfo low 24 bits: out-degree, saturating
 constexpr int MAX_LEVELS = 1 << 15;
+// bucketed push (graphs of up to MAX_BINS * BIN_SIZE nodes): increments are binned by target
+// range and reduced in LDS instead of one global atomic per edge
+constexpr int BIN_SHIFT = 13;
+constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
+constexpr int MAX_BINS = 64;
+constexpr int ACC_THREADS = 512;
+constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
+constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
 
 // error flag bits (Dev::err)
 constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4;
+
+struct PushSegQ {     // bucketed push: slice of a popped node's out-edges (slot is implicit)
+    int64_t ebeg;
+    uint64_t inc;
+    uint32_t cnt;
+    uint32_t pad;
+};
 
 struct PushSeg {      // one <=PUSH_SEG-edge slice of a popped node's out-edges
     int64_t ebeg;     // first edge (index into col)
@@ -80,6 +95,17 @@ struct Dev {
     int32_t opt;
     const int32_t *rw_idx;
     const uint64_t *idx_off, *idx_cnt;
+    // ---- bucketed push state (binned != 0)
+    int32_t binned, nbins;
+    uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
+    uint32_t *fl_count[2];  // [slot]
+    PushSegQ *segq;         // [slot][segq_cap]
+    uint32_t *segq_count;   // [slot]
+    uint64_t segq_cap;
+    uint32_t *bk_w;         // [slot][bin][bk_cap] target node of a pending increment
+    uint64_t *bk_inc;       // [slot][bin][bk_cap] its value
+    uint32_t *bk_count;     // [slot][bin]
+    uint32_t bk_cap;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -149,6 +175,23 @@ __device__ __forceinline__ void wave_append(bool flag, uint64_t item, uint64_t *
     }
 }
 
+// same for 32-bit items and a 32-bit counter (per-slot frontier lists)
+__device__ __forceinline__ void wave_append32(bool flag, uint32_t item, uint32_t *list, uint32_t *count,
+                                              uint32_t cap, uint32_t *err, uint32_t errbit) {
+    const unsigned long long mask = __ballot(flag);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (flag) {
+        const uint32_t idx = base + __popcll(mask & ((1ull << lane) - 1));
+        if (idx < cap) list[idx] = item;
+        else atomicOr(err, errbit);
+    }
+}
+
 // Philox4x32-10 (Random123 constants)
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
@@ -186,8 +229,13 @@ __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int topk_mode) {
     } else {
         d.residue[(uint64_t)q * d.n + s] = FIX_ONE;
         if (!topk_mode) {
-            unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
-            d.wl[0][i] = ((uint64_t)q << 32) | s;
+            if (d.binned) {
+                d.fl[0][(uint64_t)q * d.n] = s;
+                d.fl_count[0][q * CSTRIDE] = 1;
+            } else {
+                unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
+                d.wl[0][i] = ((uint64_t)q << 32) | s;
+            }
         }
     }
     d.qs[q] = z;
@@ -349,6 +397,283 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
     }
 }
 
+// ------------------------------------------------------------------ bucketed push
+// Same level semantics as k_push_pop / k_push_expand, reorganised so that no per-edge global
+// atomic is needed (measured: every global atomic flavour caps at ~23 G/s chip-wide, ~5 G/s
+// with power-law hot targets).  Per level:
+//   k_pushq_pop    frontier (per-slot list) -> reserve + <=256-edge slices (per-slot list)
+//   k_pushq_bin    slices -> increments binned by target range: per 2048-edge chunk an LDS
+//                  histogram, ONE global atomic per (chunk, bin) to reserve bucket space,
+//                  then coalesced-by-bin message stores
+//   k_pushq_accum  one workgroup per (slot, bin): ds_add_u64 every message into 64 KiB of LDS
+//                  accumulators, then sweep them: one plain RMW per touched node (the
+//                  workgroup owns that residue range), threshold crossing -> next frontier
+// Integer adds commute, so the result is bit-identical to the direct path and to the twin.
+
+// grid = (X, nq)
+__global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
+    const int q = blockIdx.y;
+    const int par = L & 1;
+    const uint32_t count = d.fl_count[par][q * CSTRIDE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
+    if (!count) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t *in = d.fl[par] + slab;
+    PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
+    uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
+    for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t nseg = 0;
+        uint64_t inc = 0, deg = 0;
+        int64_t beg = 0;
+        if (i < count) {
+            const uint32_t v = in[i];
+            const uint64_t a = slab + v;
+            const uint64_t r = d.residue[a];
+            d.residue[a] = 0;                                 // algo.h:985
+            const uint64_t keep = mulshift62(r, d.afix);      // v_residue * alpha
+            const uint64_t push = r - keep;                   // (1-alpha) * v_residue
+            node_row(d, v, beg, deg);
+            uint64_t res_add;
+            if (deg == 0) {                                   // algo.h:993-994
+                res_add = keep;
+                acc_dang += push;
+            } else {
+                inc = push / deg;                             // algo.h:1002
+                res_add = keep + (push - inc * deg);
+                nseg = (uint32_t)((deg + PUSH_SEG - 1) / PUSH_SEG);
+            }
+            d.ppr[a] += res_add;                              // algo.h:986-989
+            acc_res += res_add;
+            acc_pops++;
+            acc_relax += deg;
+        }
+        uint32_t tot;
+        const uint32_t off = wave_excl_scan(nseg, tot);
+        if (tot) {
+            uint32_t sb = 0;
+            if (lane == 0) sb = atomicAdd(&d.segq_count[q * CSTRIDE], tot);
+            sb = __shfl(sb, 0);
+            if ((uint64_t)sb + tot > d.segq_cap) {
+                if (lane == 0) atomicOr(d.err, ERR_SEG_OVERFLOW);
+            } else {
+                for (uint32_t k = 0; k < nseg; k++) {
+                    PushSegQ s;
+                    s.ebeg = beg + (int64_t)k * PUSH_SEG;
+                    s.inc = inc;
+                    const uint64_t left = deg - (uint64_t)k * PUSH_SEG;
+                    s.cnt = left < PUSH_SEG ? (uint32_t)left : PUSH_SEG;
+                    s.pad = 0;
+                    segs[sb + off + k] = s;
+                }
+            }
+        }
+    }
+    acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
+    acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
+    if (lane == 0 && acc_pops) {
+        QState *s = &d.qs[q];
+        atomicAdd(&s->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
+        if (acc_dang) atomicAdd(&s->dang, (unsigned long long)acc_dang);
+        atomicAdd(&s->pops, (unsigned long long)acc_pops);
+        if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
+        s->levels = (uint32_t)L + 1;
+    }
+}
+
+// grid = (X, nq)
+__global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
+    const int q = blockIdx.y;
+    const uint32_t nseg = d.segq_count[q * CSTRIDE];
+    if (!nseg) return;
+    __shared__ int64_t s_ebeg[BLOCK];
+    __shared__ uint64_t s_inc[BLOCK];
+    __shared__ uint32_t s_pref[BLOCK + 1];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS];
+    const PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
+    const uint64_t slab = (uint64_t)q * d.n;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
+    uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
+    if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
+    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nseg; tbase += gridDim.x * BLOCK) {
+        const uint32_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
+        if (i < nseg) {
+            const PushSegQ s = segs[i];
+            s_ebeg[threadIdx.x] = s.ebeg;
+            s_inc[threadIdx.x] = s.inc;
+            cnt = s.cnt;
+        }
+        uint32_t total;
+        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        __syncthreads();
+        for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
+            uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
+#pragma unroll
+            for (int k = 0; k < BIN_EPT; k++) {
+                const uint32_t e = cb + k * BLOCK + threadIdx.x;
+                w[k] = 0xFFFFFFFFu;
+                if (e < total) {
+                    uint32_t lo = 0, hi = BLOCK;
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                    }
+                    w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                    si[k] = lo;
+                    rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < (uint32_t)d.nbins) {
+                const uint32_t c = s_cnt[threadIdx.x];
+                if (c) {
+                    s_base[threadIdx.x] = atomicAdd(&bkc[threadIdx.x * CSTRIDE], c); // ONE global atomic per (chunk, bin)
+                    s_cnt[threadIdx.x] = 0;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BIN_EPT; k++) {
+                bool cross = false;
+                if (w[k] != 0xFFFFFFFFu) {
+                    const uint32_t b = w[k] >> BIN_SHIFT;
+                    const uint32_t pos = s_base[b] + rank[k];
+                    const uint64_t inc = s_inc[si[k]];
+                    if (pos < d.bk_cap) {
+                        const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
+                        d.bk_w[at] = w[k];
+                        d.bk_inc[at] = inc;
+                    } else { // bucket full: fall back to the direct atomic (same result, integer adds commute)
+                        const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w[k]],
+                                                       (unsigned long long)inc);
+                        const uint64_t thr = node_thr(d.t1, d.deg[w[k]]);
+                        cross = old < thr && old + inc >= thr;
+                    }
+                }
+                wave_append32(cross, w[k], fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid = (nbins, nq), ACC_THREADS threads
+__global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
+    __shared__ uint64_t acc[BIN_SIZE];
+    const int b = blockIdx.x, q = blockIdx.y;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t bi = (uint32_t)q * d.nbins + b;
+    uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
+    if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess went through the direct path
+    const uint32_t s = (uint32_t)d.src[q];
+    const uint64_t dm = (int)(s >> BIN_SHIFT) == b ? (uint64_t)d.qs[q].dang : 0; // algo.h:994
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d.bk_count[(uint64_t)bi * CSTRIDE] = 0;
+        if (b == 0) d.segq_count[q * CSTRIDE] = 0;
+        if (dm) d.qs[q].dang = 0;
+    }
+    if (cnt == 0 && dm == 0) return;
+    uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
+    uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
+    const uint64_t bk0 = (uint64_t)bi * d.bk_cap;
+    const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
+    if (cnt + (dm ? 1 : 0) <= ACC_THREADS / 4) {
+        // tiny bucket: zeroing and sweeping 64 KiB of LDS would cost more than a few atomics
+        bool cross = false;
+        uint32_t w = 0;
+        uint64_t inc = 0;
+        if (threadIdx.x < cnt) { w = d.bk_w[bk0 + threadIdx.x]; inc = d.bk_inc[bk0 + threadIdx.x]; }
+        else if (threadIdx.x == cnt && dm) { w = s; inc = dm; }
+        if (inc) {
+            const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)inc);
+            const uint64_t thr = node_thr(d.t1, d.deg[w]);
+            cross = old < thr && old + inc >= thr;
+        }
+        if (threadIdx.x < ACC_THREADS / 4 + 64) // whole waves only
+            wave_append32(cross, w, fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
+    __syncthreads();
+    // messages: issue ACC_UNROLL independent loads per lane before the LDS adds that consume them
+    constexpr int ACC_UNROLL = 8;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
+        uint32_t mw[ACC_UNROLL];
+        uint64_t mi[ACC_UNROLL];
+#pragma unroll
+        for (int k = 0; k < ACC_UNROLL; k++) {
+            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
+            mi[k] = 0;
+            if (i < cnt) { mw[k] = d.bk_w[bk0 + i]; mi[k] = d.bk_inc[bk0 + i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < ACC_UNROLL; k++)
+            if (mi[k]) atomicAdd((unsigned long long *)&acc[mw[k] & (BIN_SIZE - 1)], (unsigned long long)mi[k]);
+    }
+    if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
+    __syncthreads();
+    // sweep: consecutive lanes -> consecutive nodes; all loads of a lane's 16 nodes in flight together
+    constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
+    uint64_t v[SWEEP], old[SWEEP];
+    uint32_t dg[SWEEP];
+#pragma unroll
+    for (int k = 0; k < SWEEP; k++) v[k] = acc[k * ACC_THREADS + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < SWEEP; k++) {
+        old[k] = 0; dg[k] = 0;
+        if (v[k]) {
+            const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+            old[k] = d.residue[slab + node];
+            dg[k] = d.deg[node];
+        }
+    }
+    uint32_t crossmask = 0;
+#pragma unroll
+    for (int k = 0; k < SWEEP; k++) {
+        const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+        if (v[k]) {
+            d.residue[slab + node] = old[k] + v[k]; // this workgroup owns [node0, node0 + BIN_SIZE) of slot q
+            const uint64_t thr = node_thr(d.t1, dg[k]);
+            if (old[k] < thr && old[k] + v[k] >= thr) crossmask |= 1u << k; // algo.h:1012
+        }
+    }
+    // next frontier: ONE global atomic per workgroup (the per-slot counter is a hot address)
+    __shared__ uint32_t s_wtot[ACC_THREADS / 64];
+    __shared__ uint32_t s_gbase;
+    uint32_t wtot;
+    const uint32_t mine = __popc(crossmask);
+    const uint32_t wpre = wave_excl_scan(mine, wtot);
+    if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = wtot;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < ACC_THREADS / 64; w++) {
+        const uint32_t c = s_wtot[w];
+        if (w < (int)(threadIdx.x >> 6)) before += c;
+        total += c;
+    }
+    if (!total) return;
+    if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, total);
+    __syncthreads();
+    uint32_t pos = s_gbase + before + wpre;
+#pragma unroll
+    for (int k = 0; k < SWEEP; k++)
+        if (crossmask & (1u << k)) {
+            if (pos < (uint32_t)d.n) fl_next[pos] = node0 + k * ACC_THREADS + threadIdx.x;
+            else atomicOr(d.err, ERR_WL_OVERFLOW);
+            pos++;
+        }
+}
+
 // ------------------------------------------------------------------ walk allocation
 // One thread per (slot, node): num_s_rw and the weight r/num_s_rw, cut into <=WALK_SEG-walk
 // items.  grid = (chunks, nq).
@@ -459,7 +784,10 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
             const uint64_t r = d.residue[slab + v];
             in = r && r >= node_thr(d.t1, d.deg[v]);
         }
-        wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
+        if (d.binned)
+            wave_append32(in, v, d.fl[0] + slab, &d.fl_count[0][q * CSTRIDE], (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
+        else
+            wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
     }
 }
 

@@ -53,13 +53,15 @@ typedef struct {
 /* Accumulated device timings since the last reset (HIP events on the ctx stream). */
 typedef struct {
     double push_pop_ms;     /* sum over k_push_pop launches */
-    double push_expand_ms;  /* sum over k_push_expand launches (the roofline kernel) */
+    double push_expand_ms;  /* sum over k_push_expand / k_pushq_bin launches */
+    double push_accum_ms;   /* sum over k_pushq_accum launches (bucketed push only) */
     double walk_alloc_ms;   /* k_walk_alloc */
     double walk_ms;         /* k_walk */
     double other_ms;        /* init / reduce / convert kernels + memsets */
     double batch_ms;        /* whole batches, first launch to last completion */
     uint64_t push_pop_launches;
     uint64_t push_expand_launches;
+    uint64_t push_accum_launches;
     uint64_t walk_launches;
     uint64_t batches;
     uint64_t pops;          /* totals over all queries since reset */

@@ -241,3 +241,24 @@ def test_topk_argument_checks(engine, oracle, tiny):
         engine.topk(np.array([1], dtype=np.int32), 1, epsilon=0.5)     # assert(k > 1), query.h:1318
     with pytest.raises(fora_amd.ForaError):
         engine.topk(np.array([1], dtype=np.int32), 10, epsilon=0.5, with_idx=True)
+
+
+@pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow"])
+def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
+    """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
+    overflow fallback all give the twin's bits (integer adds commute)."""
+    g = small_dangling
+    if mode == "direct":
+        monkeypatch.setenv("FORA_HIP_DIRECT", "1")
+    elif mode == "bucketed_overflow":
+        monkeypatch.setenv("FORA_HIP_BKCAP", "96")
+    rmax, omega = _load(engine, g, epsilon=0.5)
+    srcs = np.concatenate([pick_sources(g, 7, 51), pick_sources(g, 1, 52, want_dangling=True)])
+    ppr, res, st = engine.query_fix(srcs)
+    for i, s in enumerate(srcs):
+        want, wres, wst = oracle.twin_query(g, int(s), rmax, omega, seed=SEED)
+        assert (res[i] == wres).all() and (ppr[i] == want).all()
+        assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["levels"] == wst["levels"]
+    monkeypatch.delenv("FORA_HIP_DIRECT", raising=False)
+    monkeypatch.delenv("FORA_HIP_BKCAP", raising=False)
+    engine.query_fix(srcs[:1])  # back to the default plan for later tests
