@@ -194,7 +194,7 @@ def main():
         walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
         out["phases"] = {
             "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"],
-            "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "other_ms": tm["other_ms"],
+            "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "walk_accum_ms": tm["walk_accum_ms"], "other_ms": tm["other_ms"],
             "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
             "walks": tm["walks"], "walk_steps": tm["walk_steps"],
             "walks_per_s": tm["walks"] / max(1e-9, tm["walk_ms"] * 1e-3),

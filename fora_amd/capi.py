@@ -35,7 +35,7 @@ class QueryStats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("push_pop_ms", C.c_double), ("push_expand_ms", C.c_double), ("push_accum_ms", C.c_double), ("walk_alloc_ms", C.c_double),
-                ("walk_ms", C.c_double), ("other_ms", C.c_double), ("batch_ms", C.c_double),
+                ("walk_ms", C.c_double), ("walk_accum_ms", C.c_double), ("other_ms", C.c_double), ("batch_ms", C.c_double),
                 ("push_pop_launches", C.c_uint64), ("push_expand_launches", C.c_uint64), ("push_accum_launches", C.c_uint64),
                 ("walk_launches", C.c_uint64), ("batches", C.c_uint64), ("pops", C.c_uint64),
                 ("relax", C.c_uint64), ("walks", C.c_uint64), ("walk_steps", C.c_uint64),

@@ -70,6 +70,7 @@ struct fora_ctx {
     uint64_t *d_bk_inc = nullptr;
     uint64_t segq_cap = 0;
     uint32_t bk_cap = 0;
+    uint32_t *d_wit_count = nullptr; // [B * CSTRIDE]
     uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
     uint8_t *d_active = nullptr;
@@ -122,7 +123,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_segq); dfree(c->d_segq_count);
-    dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count);
+    dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -131,6 +132,7 @@ void free_workspace(fora_ctx *c) {
 }
 
 constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
+static unsigned walk_grid_x(int nq) { return (unsigned)std::min(2048, std::max(8, 8192 / std::max(1, nq))); }
 
 constexpr int SPEC = 3;          // levels launched ahead of the frontier-size readback
 constexpr int FLC_RING = SPEC + 2;
@@ -143,7 +145,7 @@ static bool want_binned(const fora_ctx *c) {
 static uint32_t want_bk_cap() {
     const char *e = getenv("FORA_HIP_BKCAP");
     if (e && atoi(e) > 0) return (uint32_t)atoi(e);
-    return 65536;
+    return 163840; // walk results: ~omega*rsum/nbins per bucket (ws: ~110 k)
 }
 
 struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
@@ -182,7 +184,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
     const uint64_t n = (uint64_t)c->n;
     const uint64_t scratch = (uint64_t)B * p.scratch;
-    if (c->B >= B && c->binned == p.binned && c->seg_cap * sizeof(PushSeg) >= scratch && c->bk_cap == p.bk_cap) return FORA_OK;
+    if (c->B >= B && c->binned == p.binned && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return FORA_OK;
     free_workspace(c);
     const uint64_t slab = (uint64_t)B * n;
     HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
@@ -202,6 +204,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
     }
     HIPCHK(c, hipMalloc(&c->d_scratch, scratch));
+    HIPCHK(c, hipMalloc(&c->d_wit_count, (size_t)B * 4 * CSTRIDE));
     HIPCHK(c, hipMalloc(&c->d_counters, N_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_qs, (size_t)B * sizeof(QState)));
     HIPCHK(c, hipMalloc(&c->d_src, (size_t)B * sizeof(int32_t)));
@@ -211,7 +214,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     c->binned = p.binned; c->nbins = p.nbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
     c->wl_cap = slab;
     c->seg_cap = scratch / sizeof(PushSeg);
-    c->wit_cap = scratch / sizeof(WalkItem);
+    c->wit_cap = p.wits; // per slot
     c->h_qs.resize(B);
     return FORA_OK;
 }
@@ -228,8 +231,8 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.wit = (WalkItem *)c->d_scratch; d.wit_cap = c->wit_cap;
     d.wl_count = c->d_counters;
     d.seg_count = c->d_counters + (MAX_LEVELS + 2);
-    d.wit_count = c->d_counters + 2 * (size_t)(MAX_LEVELS + 2);
-    d.tot_steps = d.wit_count + 1;
+    d.wit_count = c->d_wit_count;
+    d.tot_steps = c->d_counters + 2 * (size_t)(MAX_LEVELS + 2) + 1;
     d.qs = c->d_qs; d.src = c->d_src; d.err = c->d_err;
     d.afix = (uint64_t)std::ldexp(c->alpha, 62);
     double t = std::ceil(std::ldexp(rmax, 62));
@@ -274,6 +277,7 @@ void ev_collect(fora_ctx *c) { // call after the stream is idle
         case 4: c->timing.other_ms += ms; break;
         case 5: c->timing.batch_ms += ms; c->timing.batches++; break;
         case 6: c->timing.push_accum_ms += ms; c->timing.push_accum_launches++; break;
+        case 7: c->timing.walk_accum_ms += ms; break;
         }
     }
     c->ev_used = 0;
@@ -312,7 +316,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
             hipLaunchKernelGGL(k_pushq_bin, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
             ev_end(c, h);
             h = ev_begin(c, 6);
-            hipLaunchKernelGGL(k_pushq_accum, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
+            hipLaunchKernelGGL(k_accum<false>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
             ev_end(c, h);
             (void)hipMemcpyAsync(c->h_flc + (size_t)((L + 1) % FLC_RING) * c->B * CSTRIDE, d.fl_count[(L + 1) & 1],
                                  (size_t)nq * 4 * CSTRIDE, hipMemcpyDeviceToHost, c->stream);
@@ -369,6 +373,7 @@ int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
     HIPCHK(c, hipMemsetAsync(c->d_ppr, 0, bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_wit_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_src, sources, (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     int rc = reset_binned_counters(c);
     ev_end(c, h);
@@ -397,9 +402,15 @@ int run_query_batch(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, 
                            (const uint8_t *)nullptr, (uint64_t *)nullptr);
         ev_end(c, h);
         h = ev_begin(c, 3);
-        hipLaunchKernelGGL(k_walk<WALK_TO_PPR>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, 0u,
+        if (with_idx) hipLaunchKernelGGL(k_walk_idx, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
+        hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d, 0u,
                            c->opt ? 1 : 0, (int32_t *)nullptr);
         ev_end(c, h);
+        if (c->binned) {
+            h = ev_begin(c, 7);
+            hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
+            ev_end(c, h);
+        }
     }
     {
         const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 64);
@@ -638,12 +649,13 @@ int fora_hip_build_index(fora_ctx *c) {
     Dev d = make_dev(c, 1, true);
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_wit_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
     const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 2048);
     int h = ev_begin(c, 4);
     hipLaunchKernelGGL(k_index_alloc, dim3(chunks), dim3(BLOCK), 0, c->stream, d);
     ev_end(c, h);
     h = ev_begin(c, 3);
-    hipLaunchKernelGGL(k_walk<WALK_TO_INDEX>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, d, 0u,
+    hipLaunchKernelGGL(k_walk_online<WALK_TO_INDEX>, dim3(walk_grid_x(1), 1), dim3(BLOCK), 0, c->stream, d, 0u,
                        c->opt ? 1 : 0, c->d_rw_idx);
     ev_end(c, h);
     rc = check_dev_err(c);
@@ -828,6 +840,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             HIPCHK(c, hipMemcpyAsync(c->d_active, active.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_above, 0, (size_t)nb * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wit_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
             rc = reset_binned_counters(c);
             if (rc) return rc;
             d = make_dev(c, nb, with_idx != 0, rmax, omega);
@@ -848,9 +861,15 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
                                (const uint8_t *)c->d_active, c->d_cursor);
             ev_end(c, h);
             h = ev_begin(c, 3);
-            hipLaunchKernelGGL(k_walk<WALK_TO_PPR>, dim3(c->grid_blocks), dim3(BLOCK), 0, c->stream, dw, (uint32_t)round,
-                               with_idx ? 1 : 0, (int32_t *)nullptr);
+            if (with_idx) hipLaunchKernelGGL(k_walk_idx, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
+            hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw,
+                               (uint32_t)round, with_idx ? 1 : 0, (int32_t *)nullptr);
             ev_end(c, h);
+            if (c->binned) {
+                h = ev_begin(c, 7);
+                hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nb), dim3(ACC_THREADS), 0, c->stream, dw, 0);
+                ev_end(c, h);
+            }
             const double T = (1 + epsilon) * delta; // query.h:1030
             h = ev_begin(c, 4);
             hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,

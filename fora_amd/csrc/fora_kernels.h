@@ -78,11 +78,11 @@ struct Dev {
     uint64_t wl_cap;
     PushSeg *seg;
     uint64_t seg_cap;
-    WalkItem *wit;
-    uint64_t wit_cap;
+    WalkItem *wit;          // [slot][wit_cap] walk items of a slot
+    uint64_t wit_cap;       // per slot
+    uint32_t *wit_count;    // [slot * CSTRIDE]
     unsigned long long *wl_count;  // [MAX_LEVELS + 2] frontier size per level
     unsigned long long *seg_count; // [MAX_LEVELS + 2]
-    unsigned long long *wit_count; // [1]
     unsigned long long *tot_steps; // [1]
     QState *qs;
     const int32_t *src; // source node per slot
@@ -565,8 +565,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     }
 }
 
-// grid = (nbins, nq), ACC_THREADS threads
-__global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
+// grid = (nbins, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
+// to the ppr slab and there is no threshold / frontier.
+template <bool TO_PPR>
+__global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint64_t acc[BIN_SIZE];
     const int b = blockIdx.x, q = blockIdx.y;
     const uint64_t slab = (uint64_t)q * d.n;
@@ -574,11 +576,12 @@ __global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
     uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
     if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess went through the direct path
     const uint32_t s = (uint32_t)d.src[q];
-    const uint64_t dm = (int)(s >> BIN_SHIFT) == b ? (uint64_t)d.qs[q].dang : 0; // algo.h:994
+    const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang : 0; // algo.h:994
+    uint64_t *target = TO_PPR ? d.ppr : d.residue;
     __syncthreads();
     if (threadIdx.x == 0) {
         d.bk_count[(uint64_t)bi * CSTRIDE] = 0;
-        if (b == 0) d.segq_count[q * CSTRIDE] = 0;
+        if (!TO_PPR && b == 0) d.segq_count[q * CSTRIDE] = 0;
         if (dm) d.qs[q].dang = 0;
     }
     if (cnt == 0 && dm == 0) return;
@@ -594,11 +597,13 @@ __global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
         if (threadIdx.x < cnt) { w = d.bk_w[bk0 + threadIdx.x]; inc = d.bk_inc[bk0 + threadIdx.x]; }
         else if (threadIdx.x == cnt && dm) { w = s; inc = dm; }
         if (inc) {
-            const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)inc);
-            const uint64_t thr = node_thr(d.t1, d.deg[w]);
-            cross = old < thr && old + inc >= thr;
+            const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
+            if (!TO_PPR) {
+                const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                cross = old < thr && old + inc >= thr;
+            }
         }
-        if (threadIdx.x < ACC_THREADS / 4 + 64) // whole waves only
+        if (!TO_PPR && threadIdx.x < ACC_THREADS / 4 + 64) // whole waves only
             wave_append32(cross, w, fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
         return;
     }
@@ -632,8 +637,8 @@ __global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
         old[k] = 0; dg[k] = 0;
         if (v[k]) {
             const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
-            old[k] = d.residue[slab + node];
-            dg[k] = d.deg[node];
+            old[k] = target[slab + node];
+            if (!TO_PPR) dg[k] = d.deg[node];
         }
     }
     uint32_t crossmask = 0;
@@ -641,11 +646,14 @@ __global__ void __launch_bounds__(ACC_THREADS) k_pushq_accum(Dev d, int L) {
     for (int k = 0; k < SWEEP; k++) {
         const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
         if (v[k]) {
-            d.residue[slab + node] = old[k] + v[k]; // this workgroup owns [node0, node0 + BIN_SIZE) of slot q
-            const uint64_t thr = node_thr(d.t1, dg[k]);
-            if (old[k] < thr && old[k] + v[k] >= thr) crossmask |= 1u << k; // algo.h:1012
+            target[slab + node] = old[k] + v[k]; // this workgroup owns [node0, node0 + BIN_SIZE) of slot q
+            if (!TO_PPR) {
+                const uint64_t thr = node_thr(d.t1, dg[k]);
+                if (old[k] < thr && old[k] + v[k] >= thr) crossmask |= 1u << k; // algo.h:1012
+            }
         }
     }
+    if (TO_PPR) return;
     // next frontier: ONE global atomic per workgroup (the per-slot counter is a hot address)
     __shared__ uint32_t s_wtot[ACC_THREADS / 64];
     __shared__ uint32_t s_gbase;
@@ -738,10 +746,10 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
         uint32_t tot;
         const uint32_t off = wave_excl_scan(nseg, tot);
         if (tot) {
-            unsigned long long sb = 0;
-            if (lane == 0) sb = atomicAdd(d.wit_count, (unsigned long long)tot);
+            uint32_t sb = 0;
+            if (lane == 0) sb = atomicAdd(&d.wit_count[q * CSTRIDE], tot);
             sb = __shfl(sb, 0);
-            if (sb + tot > d.wit_cap) {
+            if ((uint64_t)sb + tot > d.wit_cap) {
                 if (lane == 0) atomicOr(d.err, ERR_WIT_OVERFLOW);
             } else {
                 for (uint32_t k = 0; k < nseg; k++) {
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                     w.rem = rem;
                     w.q = (uint32_t)q;
                     w.v = v;
-                    d.wit[sb + off + k] = w;
+                    d.wit[(uint64_t)q * d.wit_cap + sb + off + k] = w;
                 }
             }
         }
@@ -939,6 +947,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32
 // index sizes are computed on the host (build.h:325-334); this cuts them into items
 __global__ void __launch_bounds__(BLOCK) k_index_alloc(Dev d) {
     const int lane = threadIdx.x & 63;
+    const int q = 0;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
     for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
         const uint32_t v = c * BLOCK + threadIdx.x;
@@ -948,10 +957,10 @@ __global__ void __launch_bounds__(BLOCK) k_index_alloc(Dev d) {
         uint32_t tot;
         const uint32_t off = wave_excl_scan(nseg, tot);
         if (tot) {
-            unsigned long long sb = 0;
-            if (lane == 0) sb = atomicAdd(d.wit_count, (unsigned long long)tot);
+            uint32_t sb = 0;
+            if (lane == 0) sb = atomicAdd(&d.wit_count[q * CSTRIDE], tot);
             sb = __shfl(sb, 0);
-            if (sb + tot > d.wit_cap) {
+            if ((uint64_t)sb + tot > d.wit_cap) {
                 if (lane == 0) atomicOr(d.err, ERR_WIT_OVERFLOW);
             } else {
                 for (uint32_t k = 0; k < nseg; k++) {
@@ -961,7 +970,7 @@ __global__ void __launch_bounds__(BLOCK) k_index_alloc(Dev d) {
                     w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
                     w.idx_pos = ioff + w.j0;
                     w.v = v;
-                    d.wit[sb + off + k] = w;
+                    d.wit[sb + off + k] = w; // slot 0
                 }
             }
         }
@@ -999,54 +1008,238 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
     }
 }
 
-// A block stages 256 walk items in LDS; thread t runs walks t, t+256, ... of the
-// concatenated walk range (consecutive threads = consecutive walks of one start node).
-// Each lane moves on to its next walk as soon as its current one stops, so lanes do
-// not wait for the longest walk of the wave.
-template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_walk(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
+// ---- wave-level staging of walk results for the bucketed accumulate ------------------------
+// A wave collects (dest, weight) pairs in its own LDS area; when the area is nearly full it
+// bins them by target range (LDS counters), reserves bucket space with ONE global atomic per
+// (flush, bin), and stores them.  k_accum then reduces every (slot, bin) bucket in LDS.
+constexpr int STAGE = 512; // pairs per wave
+struct WaveStage {
+    uint32_t *dest;  // [STAGE]
+    uint64_t *wgt;   // [STAGE]
+    uint32_t *bcnt;  // [MAX_BINS]
+    uint32_t *bbase; // [MAX_BINS]
+    uint32_t count;  // wave-uniform
+};
+__device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t slab = (uint64_t)q * d.n;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    st.bcnt[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t dst[STAGE / 64], rk[STAGE / 64];
+#pragma unroll
+    for (int k = 0; k < STAGE / 64; k++) {
+        const uint32_t m = k * 64 + lane;
+        dst[k] = 0xFFFFFFFFu;
+        if (m < st.count) {
+            dst[k] = st.dest[m];
+            rk[k] = atomicAdd(&st.bcnt[dst[k] >> BIN_SHIFT], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < d.nbins) {
+        const uint32_t c = st.bcnt[lane];
+        if (c) st.bbase[lane] = atomicAdd(&bkc[lane * CSTRIDE], c);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < STAGE / 64; k++) {
+        if (dst[k] != 0xFFFFFFFFu) {
+            const uint32_t b = dst[k] >> BIN_SHIFT;
+            const uint32_t pos = st.bbase[b] + rk[k];
+            const uint64_t w = st.wgt[k * 64 + lane];
+            if (pos < d.bk_cap) {
+                const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
+                d.bk_w[at] = dst[k];
+                d.bk_inc[at] = w;
+            } else { // bucket full: direct atomic, same sum
+                atomicAdd((unsigned long long *)&d.ppr[slab + dst[k]], (unsigned long long)w);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    st.count = 0;
+}
+__device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, bool has, uint32_t dest, uint64_t w) {
+    const unsigned long long mask = __ballot(has);
+    if (!mask) return;
+    if (has) {
+        const uint32_t pos = st.count + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1));
+        st.dest[pos] = dest;
+        st.wgt[pos] = w;
+    }
+    st.count += (uint32_t)__popcll(mask);
+    if (st.count > STAGE - 64) stage_flush(d, q, st);
+}
+#define WAVE_STAGE_DECL(st)                                                                         \
+    __shared__ uint32_t st##_dest[BLOCK / 64][STAGE];                                               \
+    __shared__ uint64_t st##_wgt[BLOCK / 64][STAGE];                                                \
+    __shared__ uint32_t st##_bcnt[BLOCK / 64][MAX_BINS], st##_bbase[BLOCK / 64][MAX_BINS];         \
+    WaveStage st;                                                                                   \
+    st.dest = st##_dest[threadIdx.x >> 6]; st.wgt = st##_wgt[threadIdx.x >> 6];                     \
+    st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6]; st.count = 0;
+
+// ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
+// are read from rw_idx.  Streaming gather; grid = (X, nq).
+__global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
-    __shared__ uint32_t s_q[BLOCK], s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
-    const uint64_t count = *d.wit_count;
-    uint32_t steps = 0;
-    for (uint64_t tbase = (uint64_t)blockIdx.x * BLOCK; tbase < count; tbase += (uint64_t)gridDim.x * BLOCK) {
-        const uint64_t i = tbase + threadIdx.x;
+    __shared__ uint32_t s_pref[BLOCK + 1], s_w[4];
+    const int q = blockIdx.y;
+    const uint32_t nitems = d.wit_count[q * CSTRIDE];
+    if (!nitems) return;
+    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const uint64_t slab = (uint64_t)q * d.n;
+    WAVE_STAGE_DECL(st)
+    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
+        const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
-        if (i < count) {
-            const WalkItem w = d.wit[i];
+        if (i < nitems) {
+            const WalkItem w = items[i];
             s_j0[threadIdx.x] = w.j0; s_pos[threadIdx.x] = w.idx_pos;
             s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
-            s_q[threadIdx.x] = w.q; s_v[threadIdx.x] = w.v; s_idxn[threadIdx.x] = w.idx_n;
-            cnt = w.cnt;
+            cnt = w.idx_n;
         }
         uint32_t total;
         const uint32_t pre = block_excl_scan(cnt, s_w, total);
         s_pref[threadIdx.x] = pre;
         if (threadIdx.x == 0) s_pref[BLOCK] = total;
         __syncthreads();
-        for (uint32_t e = threadIdx.x; e < total; e += BLOCK) {
-            uint32_t lo = 0, hi = BLOCK;
+        for (uint32_t eb = 0; eb < total; eb += BLOCK) {
+            const uint32_t e = eb + threadIdx.x;
+            const bool has = e < total;
+            uint32_t dest = 0;
+            uint64_t wgt = 0;
+            if (has) {
+                uint32_t lo = 0, hi = BLOCK;
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                const uint32_t jj = e - s_pref[lo];
+                const uint64_t j = s_j0[lo] + jj;
+                dest = (uint32_t)d.rw_idx[s_pos[lo] + jj];          // query.h:292
+                wgt = s_incr[lo] + (j < s_rem[lo] ? 1 : 0);         // query.h:293
+            }
+            if (d.binned) stage_emit(d, q, st, has, dest, wgt);
+            else if (has) atomicAdd((unsigned long long *)&d.ppr[slab + dest], (unsigned long long)wgt);
+        }
+        __syncthreads();
+    }
+    if (d.binned && st.count) stage_flush(d, q, st);
+}
+
+// ---- online walks (query.h:297-300, 320-323; build.h:344-354).  grid = (X, nq).
+// A block stages 256 items of one slot in LDS; each of its 4 waves owns a contiguous quarter
+// of the tile's walks and hands them out dynamically: every second iteration idle lanes
+// (ballot + prefix popcount) take the next walk numbers of the wave's range, so no lane waits
+// for the longest walk of the wave.  Walks start on even iterations only, hence all running
+// walks of a wave share step parity and the Philox call (one per two steps) is wave-uniform.
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
+    __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
+    __shared__ uint32_t s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
+    const int q = blockIdx.y;
+    const uint32_t nitems = d.wit_count[q * CSTRIDE];
+    if (!nitems) return;
+    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t stream = MODE == WALK_TO_INDEX ? 0xFFFFFFFFu : (uint32_t)d.src[q];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t steps = 0;
+    WAVE_STAGE_DECL(st)
+    const bool staged = MODE == WALK_TO_PPR && d.binned;
+    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
+        const uint32_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
+        if (i < nitems) {
+            const WalkItem w = items[i];
+            s_j0[threadIdx.x] = w.j0; s_pos[threadIdx.x] = w.idx_pos;
+            s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
+            s_v[threadIdx.x] = w.v;
+            const uint32_t in_idx = MODE == WALK_TO_INDEX ? 0u : w.idx_n;
+            s_idxn[threadIdx.x] = in_idx;
+            cnt = w.cnt - in_idx;
+        }
+        uint32_t total;
+        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        __syncthreads();
+        const uint32_t wend = (uint32_t)(((uint64_t)total * (wid + 1)) >> 2);
+        uint32_t wptr = (uint32_t)(((uint64_t)total * wid) >> 2); // next unassigned walk of this wave
+        uint32_t cur_item = 0;                                       // item holding walk wptr (wave-uniform)
+        {
+            uint32_t hi = BLOCK;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                const uint32_t mid = (cur_item + hi) >> 1;
+                if (s_pref[mid] <= wptr) cur_item = mid; else hi = mid;
             }
-            const uint32_t jj = e - s_pref[lo];
-            const uint64_t j = s_j0[lo] + jj;
-            const uint32_t v = s_v[lo];
-            if (MODE == WALK_TO_INDEX) {
-                idx_out[s_pos[lo] + jj] = walk_one(d, v, j, 0xFFFFFFFFu, 0, nzh, steps); // build.h:346-353
-            } else {
-                const uint32_t q = s_q[lo];
-                int32_t dest;
-                if (jj < s_idxn[lo]) dest = d.rw_idx[s_pos[lo] + jj];                  // query.h:291-293
-                else dest = walk_one(d, v, j, (uint32_t)d.src[q], round, nzh, steps);   // query.h:298,321
-                atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + (uint32_t)dest],
-                          (unsigned long long)(s_incr[lo] + (j < s_rem[lo] ? 1 : 0)));  // query.h:299,322
+        }
+        bool active = false;
+        uint32_t cur = 0, start = 0, t = 0;
+        uint64_t wj = 0, wgt = 0, opos = 0, deg0 = 0;
+        int64_t beg0 = 0;
+        uint32_t rw[4] = {0, 0, 0, 0};
+        for (uint32_t it = 0;; it++) {
+            int32_t done = -1; // endpoint to emit this iteration
+            if ((it & 1u) == 0) {
+                const unsigned long long idle = __ballot(!active);
+                const uint32_t avail = wend - wptr;
+                if (!avail && idle == ~0ull) break;
+                if (avail && idle) {
+                    const uint32_t rank = __popcll(idle & ((1ull << lane) - 1));
+                    if (!active && rank < avail) {
+                        const uint32_t e = wptr + rank;
+                        uint32_t item = cur_item;
+                        while (s_pref[item + 1] <= e) item++;
+                        const uint32_t jj = s_idxn[item] + (e - s_pref[item]); // online walks follow the indexed ones
+                        wj = s_j0[item] + jj;
+                        start = s_v[item];
+                        if (MODE == WALK_TO_INDEX) opos = s_pos[item] + jj;
+                        else wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0);
+                        node_row(d, start, beg0, deg0);
+                        cur = start;
+                        t = 0;
+                        if (deg0 == 0) done = (int32_t)start; // algo.h:127-129
+                        else active = true;
+                    }
+                    const uint32_t want = (uint32_t)__popcll(idle);
+                    wptr += want < avail ? want : avail;
+                    while (wptr < wend && s_pref[cur_item + 1] <= wptr) cur_item++;
+                }
+                if (active)
+                    philox4x32_10(start, (uint32_t)wj,
+                                  (uint32_t)((wj >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
+                                  stream, d.seed_lo, d.seed_hi, rw);
+            }
+            if (active) {
+                const uint32_t ws = (it & 1u) ? rw[2] : rw[0], wm = (it & 1u) ? rw[3] : rw[1];
+                if (!(nzh && t == 0) && ws < d.alpha32) { // algo.h:131-133
+                    done = (int32_t)cur;
+                    active = false;
+                } else {
+                    int64_t b = beg0;
+                    uint64_t dg = deg0;
+                    if (t) node_row(d, cur, b, dg);
+                    if (dg > 0) cur = (uint32_t)d.col[b + (int64_t)(((uint64_t)wm * dg) >> 32)]; // algo.h:134-137
+                    else cur = start;                                                            // algo.h:138-140
+                    t++;
+                    steps++;
+                }
+            }
+            if (staged) {
+                stage_emit(d, q, st, done >= 0, (uint32_t)done, wgt);                             // query.h:299,322
+            } else if (done >= 0) {
+                if (MODE == WALK_TO_INDEX) idx_out[opos] = done;                                  // build.h:346-353
+                else atomicAdd((unsigned long long *)&d.ppr[slab + (uint32_t)done], (unsigned long long)wgt);
             }
         }
         __syncthreads();
     }
+    if (staged && st.count) stage_flush(d, q, st);
     const uint64_t ws = wave_sum((uint64_t)steps);
     if ((threadIdx.x & 63) == 0 && ws) atomicAdd(d.tot_steps, (unsigned long long)ws);
 }

@@ -56,7 +56,8 @@ typedef struct {
     double push_expand_ms;  /* sum over k_push_expand / k_pushq_bin launches */
     double push_accum_ms;   /* sum over k_pushq_accum launches (bucketed push only) */
     double walk_alloc_ms;   /* k_walk_alloc */
-    double walk_ms;         /* k_walk */
+    double walk_ms;         /* k_walk_idx + k_walk_online */
+    double walk_accum_ms;   /* k_accum<to ppr> (bucketed path only) */
     double other_ms;        /* init / reduce / convert kernels + memsets */
     double batch_ms;        /* whole batches, first launch to last completion */
     uint64_t push_pop_launches;
