@@ -80,6 +80,13 @@ struct fora_ctx {
     int topk_cap = 0;
     unsigned long long *h_pinned = nullptr; // [MAX_LEVELS + 2] frontier sizes read back
     std::vector<QState> h_qs;
+    QState *h_qs_pin = nullptr;              // pinned landing area of the per-slot accumulators
+    unsigned long long *h_steps_pin = nullptr;
+    // second lane: own stream + workspace, shares graph / index / params; lets the push of batch
+    // k+1 overlap the (fabric-bound) walks of batch k
+    fora_ctx *twin = nullptr;
+    bool is_twin = false;
+    int pending_nq = 0;                      // batch enqueued on this lane, not yet finished
 
     // timing
     bool profiling = true;
@@ -128,6 +135,10 @@ void free_workspace(fora_ctx *c) {
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     c->h_pinned = nullptr;
+    if (c->h_qs_pin) (void)hipHostFree(c->h_qs_pin);
+    c->h_qs_pin = nullptr;
+    if (c->h_steps_pin) (void)hipHostFree(c->h_steps_pin);
+    c->h_steps_pin = nullptr;
     c->B = 0;
 }
 
@@ -177,7 +188,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (B == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
-        uint64_t budget = (uint64_t)(fr * 0.6);
+        uint64_t budget = (uint64_t)(fr * 0.4); // a second lane may hold its own workspace
         B = (int)std::min<uint64_t>(256, std::max<uint64_t>(1, budget / p.per_slot));
     }
     B = std::max(1, B);
@@ -210,6 +221,8 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipMalloc(&c->d_src, (size_t)B * sizeof(int32_t)));
     HIPCHK(c, hipMalloc(&c->d_err, sizeof(uint32_t)));
     HIPCHK(c, hipHostMalloc(&c->h_pinned, (MAX_LEVELS + 2) * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&c->h_qs_pin, (size_t)B * sizeof(QState)));
+    HIPCHK(c, hipHostMalloc(&c->h_steps_pin, sizeof(unsigned long long)));
     c->B = B;
     c->binned = p.binned; c->nbins = p.nbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
     c->wl_cap = slab;
@@ -383,7 +396,9 @@ int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
 enum { RUN_PUSH_ONLY = 1 };
 
 // one batch of <= B sources: push (+ refinement).  Results stay in the slabs.
-int run_query_batch(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int flags) {
+// one batch of <= B sources, part 1: push (host-driven level loop, returns when the push is done)
+// and everything after it enqueued on the lane's stream.  Results stay in the slabs.
+int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int flags) {
     for (int i = 0; i < nq; i++)
         if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
     const int hb = ev_begin(c, 5);
@@ -418,16 +433,24 @@ int run_query_batch(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, 
         hipLaunchKernelGGL(k_ppr_sum, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d);
         ev_end(c, h);
     }
-    unsigned long long steps = 0;
-    HIPCHK(c, hipMemcpyAsync(c->h_qs.data(), c->d_qs, (size_t)nq * sizeof(QState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&steps, d.tot_steps, sizeof(steps), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_qs_pin, c->d_qs, (size_t)nq * sizeof(QState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_steps_pin, d.tot_steps, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     ev_end(c, hb);
-    rc = check_dev_err(c);
+    c->pending_nq = nq;
+    return FORA_OK;
+}
+
+// part 2: wait for the lane, check device flags, fold timings and counters
+int batch_finish(fora_ctx *c) {
+    const int nq = c->pending_nq;
+    c->pending_nq = 0;
+    int rc = check_dev_err(c);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("batch: ") + hipGetErrorString(e));
     ev_collect(c);
-    c->timing.walk_steps += steps;
+    for (int i = 0; i < nq; i++) c->h_qs[i] = c->h_qs_pin[i];
+    c->timing.walk_steps += *c->h_steps_pin;
     for (int i = 0; i < nq; i++) {
         c->timing.pops += c->h_qs[i].pops;
         c->timing.relax += c->h_qs[i].relax;
@@ -448,6 +471,31 @@ void fill_stats(const fora_ctx *c, int nq, fora_query_stats *out) {
     }
 }
 
+// (re)creates the second lane and mirrors graph / index / params into it (non-owning pointers)
+int sync_twin(fora_ctx *c) {
+    if (!c->twin) {
+        fora_ctx *w = new (std::nothrow) fora_ctx();
+        if (!w) return fail(c, FORA_E_NOMEM, "twin lane");
+        w->is_twin = true;
+        w->device = c->device;
+        w->prop = c->prop;
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return fail(c, FORA_E_HIP, "twin stream"); }
+        w->profiling = c->profiling;
+        w->grid_blocks = c->grid_blocks;
+        c->twin = w;
+    }
+    fora_ctx *w = c->twin;
+    if (w->n != c->n || w->d_col != c->d_col) free_workspace(w);
+    w->n = c->n; w->m_attr = c->m_attr; w->nnz = c->nnz;
+    w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
+    w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
+    w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
+    w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
+    w->idx_len = c->idx_len; w->have_index = c->have_index;
+    w->batch_req = c->B; // same slot count as the first lane
+    return FORA_OK;
+}
+
 int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int flags, double *ppr_d,
                  uint64_t *ppr_fix, uint64_t *residue_fix, fora_query_stats *stats) {
     if (!c) return FORA_E_ARG;
@@ -459,24 +507,56 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
     int rc = ensure_workspace(c, nq, c->omega);
     if (rc) return rc;
     const uint64_t n = (uint64_t)c->n;
-    for (int b0 = 0; b0 < nq; b0 += c->B) {
-        const int nb = std::min(c->B, nq - b0);
-        rc = run_query_batch(c, sources + b0, nb, with_idx != 0, flags);
+    // second lane when there is more than one batch to run
+    fora_ctx *lanes[2] = {c, c};
+    const char *pe = getenv("FORA_HIP_PIPELINE");
+    if (nq > c->B && pe && pe[0] == '1') { // opt-in: measured no gain on ws (kernels time-slice)
+        rc = sync_twin(c);
         if (rc) return rc;
-        if (stats) fill_stats(c, nb, stats + b0);
-        const uint64_t bytes = (uint64_t)nb * n * 8;
+        rc = ensure_workspace(c->twin, c->B, c->omega);
+        if (rc) { c->err = c->twin->err; return rc; }
+        if (c->twin->B >= c->B) lanes[1] = c->twin;
+    }
+    struct Pending { fora_ctx *lane; int b0, nb; };
+    std::vector<Pending> inflight;
+    auto finish = [&](const Pending &p) -> int {
+        int r = batch_finish(p.lane);
+        if (r) { if (p.lane != c) c->err = p.lane->err; return r; }
+        if (stats) fill_stats(p.lane, p.nb, stats + p.b0);
+        const uint64_t bytes = (uint64_t)p.nb * n * 8;
         if (ppr_d) {
             // u64 and f64 have the same size: copy raw, convert in place on the host
-            double *dst = ppr_d + (uint64_t)b0 * n;
-            HIPCHK(c, hipMemcpy(dst, c->d_ppr, bytes, hipMemcpyDeviceToHost));
+            double *dst = ppr_d + (uint64_t)p.b0 * n;
+            HIPCHK(c, hipMemcpy(dst, p.lane->d_ppr, bytes, hipMemcpyDeviceToHost));
             uint64_t *raw = (uint64_t *)dst;
-            for (uint64_t i = 0; i < (uint64_t)nb * n; i++) {
+            for (uint64_t i = 0; i < (uint64_t)p.nb * n; i++) {
                 uint64_t u = raw[i];
                 dst[i] = std::ldexp((double)u, -62);
             }
         }
-        if (ppr_fix) HIPCHK(c, hipMemcpy(ppr_fix + (uint64_t)b0 * n, c->d_ppr, bytes, hipMemcpyDeviceToHost));
-        if (residue_fix) HIPCHK(c, hipMemcpy(residue_fix + (uint64_t)b0 * n, c->d_residue, bytes, hipMemcpyDeviceToHost));
+        if (ppr_fix) HIPCHK(c, hipMemcpy(ppr_fix + (uint64_t)p.b0 * n, p.lane->d_ppr, bytes, hipMemcpyDeviceToHost));
+        if (residue_fix) HIPCHK(c, hipMemcpy(residue_fix + (uint64_t)p.b0 * n, p.lane->d_residue, bytes, hipMemcpyDeviceToHost));
+        return FORA_OK;
+    };
+    int k = 0;
+    for (int b0 = 0; b0 < nq; b0 += c->B, k++) {
+        const int nb = std::min(c->B, nq - b0);
+        fora_ctx *lane = lanes[k & 1];
+        // the lane's previous batch must be drained before its workspace is reused
+        for (size_t i = 0; i < inflight.size();) {
+            if (inflight[i].lane == lane) {
+                rc = finish(inflight[i]);
+                if (rc) return rc;
+                inflight.erase(inflight.begin() + (long)i);
+            } else i++;
+        }
+        rc = batch_begin(lane, sources + b0, nb, with_idx != 0, flags);
+        if (rc) { if (lane != c) c->err = lane->err; return rc; }
+        inflight.push_back({lane, b0, nb});
+    }
+    for (const Pending &p : inflight) {
+        rc = finish(p);
+        if (rc) return rc;
     }
     return FORA_OK;
 }
@@ -518,6 +598,15 @@ void fora_hip_destroy(fora_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->twin) {
+        fora_ctx *w = c->twin;
+        if (w->stream) (void)hipStreamSynchronize(w->stream);
+        free_workspace(w);
+        for (auto &p : w->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        if (w->stream) (void)hipStreamDestroy(w->stream);
+        delete w; // graph / index pointers are owned by c
+        c->twin = nullptr;
+    }
     free_workspace(c);
     free_index(c);
     free_graph(c);
@@ -547,6 +636,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
         if (col[e] < 0 || col[e] >= n) return fail(c, FORA_E_ARG, "edge target out of range"); // graph.h:155-156
     HIPCHK(c, hipSetDevice(c->device));
     free_workspace(c);
+    if (c->twin) free_workspace(c->twin);
     free_index(c);
     free_graph(c);
     std::vector<uint64_t> rowinfo((size_t)n);
@@ -603,7 +693,7 @@ int fora_hip_get_params(fora_ctx *c, double *rmax, double *omega) {
 
 int fora_hip_set_batch(fora_ctx *c, int batch) {
     if (!c || batch < 0) return FORA_E_ARG;
-    if (batch != c->batch_req) { (void)hipSetDevice(c->device); free_workspace(c); }
+    if (batch != c->batch_req) { (void)hipSetDevice(c->device); free_workspace(c); if (c->twin) free_workspace(c->twin); }
     c->batch_req = batch;
     return FORA_OK;
 }
@@ -905,11 +995,21 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
 int fora_hip_reset_timing(fora_ctx *c) {
     if (!c) return FORA_E_ARG;
     c->timing = fora_timing{};
+    if (c->twin) c->twin->timing = fora_timing{};
     return FORA_OK;
 }
 int fora_hip_get_timing(fora_ctx *c, fora_timing *out) {
     if (!c || !out) return FORA_E_ARG;
     *out = c->timing;
+    if (c->twin) {
+        const fora_timing &w = c->twin->timing;
+        out->push_pop_ms += w.push_pop_ms; out->push_expand_ms += w.push_expand_ms; out->push_accum_ms += w.push_accum_ms;
+        out->walk_alloc_ms += w.walk_alloc_ms; out->walk_ms += w.walk_ms; out->walk_accum_ms += w.walk_accum_ms;
+        out->other_ms += w.other_ms; out->batch_ms += w.batch_ms;
+        out->push_pop_launches += w.push_pop_launches; out->push_expand_launches += w.push_expand_launches;
+        out->push_accum_launches += w.push_accum_launches; out->walk_launches += w.walk_launches; out->batches += w.batches;
+        out->pops += w.pops; out->relax += w.relax; out->walks += w.walks; out->walk_steps += w.walk_steps; out->levels += w.levels;
+    }
     return FORA_OK;
 }
 

@@ -262,3 +262,18 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     monkeypatch.delenv("FORA_HIP_DIRECT", raising=False)
     monkeypatch.delenv("FORA_HIP_BKCAP", raising=False)
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
+
+
+def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
+    """Opt-in second lane (push of batch k+1 overlapping walks of batch k) gives the same bits."""
+    g = small
+    _load(engine, g, epsilon=0.5)
+    srcs = pick_sources(g, 10, 61)
+    engine.set_batch(3)
+    a, ra, _ = engine.query_fix(srcs)
+    monkeypatch.setenv("FORA_HIP_PIPELINE", "1")
+    b, rb, st = engine.query_fix(srcs)
+    monkeypatch.delenv("FORA_HIP_PIPELINE")
+    engine.set_batch(0)
+    assert (a == b).all() and (ra == rb).all()
+    assert all(s["ppr_sum_fix"] == oracle.FIX_ONE for s in st)
