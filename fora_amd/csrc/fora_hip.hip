@@ -66,6 +66,7 @@ struct fora_ctx {
     int nbins = 0;
     uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
     PushSegQ *d_segq = nullptr;
+    uint64_t *d_inc_tab = nullptr;
     uint32_t *d_segq_count = nullptr, *d_bk_w = nullptr, *d_bk_count = nullptr;
     uint64_t *d_bk_inc = nullptr;
     uint64_t segq_cap = 0;
@@ -129,7 +130,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     c->topk_cap = 0;
-    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_segq); dfree(c->d_segq_count);
+    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_segq); dfree(c->d_inc_tab); dfree(c->d_segq_count);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
@@ -151,7 +152,9 @@ constexpr int FLC_RING = SPEC + 2;
 static bool want_binned(const fora_ctx *c) {
     const char *e = getenv("FORA_HIP_DIRECT");
     if (e && e[0] == '1') return false;
-    return (uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE;
+    // push messages carry the slice index in SEG_BITS bits
+    const uint64_t segs = (uint64_t)c->n + (uint64_t)c->nnz / PUSH_SEG + 64;
+    return (uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && segs <= (1ull << SEG_BITS);
 }
 static uint32_t want_bk_cap() {
     const char *e = getenv("FORA_HIP_BKCAP");
@@ -173,7 +176,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
         p.bk_cap = want_bk_cap();
         p.segq_cap = p.segs;
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * sizeof(PushSegQ) + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * (sizeof(PushSegQ) + 8) + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -205,6 +208,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_fl[1], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
         HIPCHK(c, hipMalloc(&c->d_segq, (uint64_t)B * p.segq_cap * sizeof(PushSegQ)));
+        HIPCHK(c, hipMalloc(&c->d_inc_tab, (uint64_t)B * p.segq_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_segq_count, (size_t)B * 4 * CSTRIDE));
         HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.nbins * p.bk_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.nbins * p.bk_cap * 8));
@@ -256,7 +260,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.binned = c->binned ? 1 : 0; d.nbins = c->nbins;
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
-    d.segq = c->d_segq; d.segq_count = c->d_segq_count; d.segq_cap = c->segq_cap;
+    d.segq = c->d_segq; d.inc_tab = c->d_inc_tab; d.segq_count = c->d_segq_count; d.segq_cap = c->segq_cap;
     d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;

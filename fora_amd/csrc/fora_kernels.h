@@ -28,6 +28,7 @@ constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 ac
 constexpr int MAX_BINS = 64;
 constexpr int ACC_THREADS = 512;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
+constexpr int SEG_BITS = 32 - BIN_SHIFT; // push message = (target & (BIN_SIZE-1)) << SEG_BITS | slice index
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
 
 // error flag bits (Dev::err)
@@ -100,6 +101,7 @@ struct Dev {
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
     PushSegQ *segq;         // [slot][segq_cap]
+    uint64_t *inc_tab;      // [slot][segq_cap] increment of slice i (compact: gathered by k_accum)
     uint32_t *segq_count;   // [slot]
     uint64_t segq_cap;
     uint32_t *bk_w;         // [slot][bin][bk_cap] target node of a pending increment
@@ -466,6 +468,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
                     s.cnt = left < PUSH_SEG ? (uint32_t)left : PUSH_SEG;
                     s.pad = 0;
                     segs[sb + off + k] = s;
+                    d.inc_tab[(uint64_t)q * d.segq_cap + sb + off + k] = inc;
                 }
             }
         }
@@ -514,18 +517,25 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
         if (threadIdx.x == 0) s_pref[BLOCK] = total;
         __syncthreads();
         for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
+            // each lane takes BIN_EPT consecutive edges: one binary search, then a linear walk over
+            // the slice boundaries; the lane's loads fall into one or two cache lines
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
+            const uint32_t e0 = cb + threadIdx.x * BIN_EPT;
+            uint32_t lo = 0;
+            if (e0 < total) {
+                uint32_t hi = BLOCK;
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= e0) lo = mid; else hi = mid;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
-                const uint32_t e = cb + k * BLOCK + threadIdx.x;
+                const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
                 if (e < total) {
-                    uint32_t lo = 0, hi = BLOCK;
-#pragma unroll
-                    for (int it = 0; it < 8; it++) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= e) lo = mid; else hi = mid;
-                    }
+                    while (s_pref[lo + 1] <= e) lo++;
                     w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
                     si[k] = lo;
                     rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
@@ -546,12 +556,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                 if (w[k] != 0xFFFFFFFFu) {
                     const uint32_t b = w[k] >> BIN_SHIFT;
                     const uint32_t pos = s_base[b] + rank[k];
-                    const uint64_t inc = s_inc[si[k]];
                     if (pos < d.bk_cap) {
-                        const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
-                        d.bk_w[at] = w[k];
-                        d.bk_inc[at] = inc;
+                        d.bk_w[bk0 + (uint64_t)b * d.bk_cap + pos] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
                     } else { // bucket full: fall back to the direct atomic (same result, integer adds commute)
+                        const uint64_t inc = s_inc[si[k]];
                         const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w[k]],
                                                        (unsigned long long)inc);
                         const uint64_t thr = node_thr(d.t1, d.deg[w[k]]);
@@ -594,8 +602,14 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         bool cross = false;
         uint32_t w = 0;
         uint64_t inc = 0;
-        if (threadIdx.x < cnt) { w = d.bk_w[bk0 + threadIdx.x]; inc = d.bk_inc[bk0 + threadIdx.x]; }
-        else if (threadIdx.x == cnt && dm) { w = s; inc = dm; }
+        if (threadIdx.x < cnt) {
+            w = d.bk_w[bk0 + threadIdx.x];
+            if (TO_PPR) inc = d.bk_inc[bk0 + threadIdx.x];
+            else {
+                inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
+                w = node0 + (w >> SEG_BITS);
+            }
+        } else if (threadIdx.x == cnt && dm) { w = s; inc = dm; }
         if (inc) {
             const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
             if (!TO_PPR) {
@@ -618,7 +632,19 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
             mi[k] = 0;
-            if (i < cnt) { mw[k] = d.bk_w[bk0 + i]; mi[k] = d.bk_inc[bk0 + i]; }
+            mw[k] = 0;
+            if (i < cnt) {
+                mw[k] = d.bk_w[bk0 + i];
+                if (TO_PPR) mi[k] = d.bk_inc[bk0 + i];
+            }
+        }
+        if (!TO_PPR) { // push message: target (BIN_SHIFT bits) | slice index (SEG_BITS bits)
+#pragma unroll
+            for (int k = 0; k < ACC_UNROLL; k++) {
+                const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
+                if (i < cnt) mi[k] = d.inc_tab[(uint64_t)q * d.segq_cap + (mw[k] & ((1u << SEG_BITS) - 1))];
+                mw[k] >>= SEG_BITS;
+            }
         }
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++)
