@@ -39,6 +39,8 @@ struct fora_ctx {
     int32_t *d_col = nullptr;
     uint64_t *d_rowinfo = nullptr;
     uint32_t *d_deg = nullptr;
+    uint32_t *d_rp32 = nullptr, *d_colp = nullptr;
+    uint32_t colbits = 0;
 
     // params
     bool have_params = false;
@@ -118,7 +120,7 @@ template <typename T> void dfree(T *&p) {
 }
 
 void free_graph(fora_ctx *c) {
-    dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg);
+    dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp);
     c->n = 0; c->nnz = 0;
 }
 void free_index(fora_ctx *c) {
@@ -242,6 +244,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     Dev d{};
     d.n = c->n; d.nq = nq;
     d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col; d.deg = c->d_deg;
+    d.rp32 = c->d_rp32; d.colp = c->d_colp; d.colbits = c->colbits;
     d.residue = c->d_residue; d.ppr = c->d_ppr;
     d.wl[0] = c->d_wl[0]; d.wl[1] = c->d_wl[1]; d.wl_cap = c->wl_cap;
     d.seg = (PushSeg *)c->d_scratch; d.seg_cap = c->seg_cap;
@@ -492,6 +495,7 @@ int sync_twin(fora_ctx *c) {
     if (w->n != c->n || w->d_col != c->d_col) free_workspace(w);
     w->n = c->n; w->m_attr = c->m_attr; w->nnz = c->nnz;
     w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
+    w->d_rp32 = c->d_rp32; w->d_colp = c->d_colp; w->colbits = c->colbits;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
@@ -659,6 +663,27 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     if (nnz) HIPCHK(c, hipMemcpy(c->d_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_rowinfo, rowinfo.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_deg, deg.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    const char *nc = getenv("FORA_HIP_NO_COMPACT");
+    if (nnz < (1ll << 31) && !(nc && nc[0] == '1')) { // compact walk-step copy
+        uint32_t bits = 1;
+        while ((1ull << bits) < (uint64_t)n) bits++;
+        if (bits > 31) bits = 31;
+        std::vector<uint32_t> rp32((size_t)n + 1);
+        for (int32_t v = 0; v <= n; v++) rp32[v] = (uint32_t)row_ptr[v];
+        const size_t words = (size_t)(((uint64_t)nnz * bits + 31) / 32) + 2;
+        std::vector<uint32_t> pk(words, 0);
+        for (int64_t e = 0; e < nnz; e++) {
+            const uint64_t at = (uint64_t)e * bits;
+            const uint64_t x = (uint64_t)(uint32_t)col[e] << (at & 31);
+            pk[at >> 5] |= (uint32_t)x;
+            pk[(at >> 5) + 1] |= (uint32_t)(x >> 32);
+        }
+        HIPCHK(c, hipMalloc(&c->d_rp32, rp32.size() * 4));
+        HIPCHK(c, hipMalloc(&c->d_colp, words * 4));
+        HIPCHK(c, hipMemcpy(c->d_rp32, rp32.data(), rp32.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_colp, pk.data(), words * 4, hipMemcpyHostToDevice));
+        c->colbits = bits;
+    }
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
     return FORA_OK;

@@ -74,6 +74,12 @@ struct Dev {
     const int64_t *row_ptr;
     const int32_t *col;
     const uint32_t *deg;
+    // compact copy for the walk steps (nnz < 2^31): 32-bit row offsets and ceil(log2 n)-bit packed
+    // column entries shrink the randomly gathered working set (ws: 11.2 MB -> 6.6 MB) for a better
+    // L2 hit rate -- the walk kernel is bound by L2 misses, each of which moves a 64-B line
+    const uint32_t *rp32;   // [n + 1] or null
+    const uint32_t *colp;   // bit-packed column ids, entry e at bit e*colbits, read as two aligned dwords
+    uint32_t colbits;
     uint64_t *residue, *ppr;
     uint64_t *wl[2];
     uint64_t wl_cap;
@@ -128,6 +134,23 @@ __device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg,
     beg = (int64_t)(ri >> 24);
     deg = ri & DEG_SAT;
     if (deg == DEG_SAT) deg = (uint64_t)(d.row_ptr[v + 1] - beg);
+}
+
+// one walk move from `cur` with random word wm: returns the chosen out-neighbour, or `start` when
+// cur is dangling (algo.h:134-140)
+__device__ __forceinline__ uint32_t walk_move(const Dev &d, uint32_t cur, uint32_t start, uint32_t wm) {
+    if (d.rp32) {
+        const uint32_t b = d.rp32[cur], dg = d.rp32[cur + 1] - b;
+        if (!dg) return start;
+        const uint64_t at = (uint64_t)d.colbits * (b + __umulhi(wm, dg)); // bit offset of the entry
+        const uint32_t wlo = d.colp[at >> 5], whi = d.colp[(at >> 5) + 1];
+        const uint64_t both = ((uint64_t)whi << 32) | wlo;
+        return (uint32_t)(both >> (at & 31)) & ((1u << d.colbits) - 1u);
+    }
+    int64_t beg; uint64_t deg;
+    node_row(d, cur, beg, deg);
+    if (!deg) return start;
+    return (uint32_t)d.col[beg + (int64_t)(((uint64_t)wm * deg) >> 32)];
 }
 
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
@@ -1247,11 +1270,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, in
                     done = (int32_t)cur;
                     active = false;
                 } else {
-                    int64_t b = beg0;
-                    uint64_t dg = deg0;
-                    if (t) node_row(d, cur, b, dg);
-                    if (dg > 0) cur = (uint32_t)d.col[b + (int64_t)(((uint64_t)wm * dg) >> 32)]; // algo.h:134-137
-                    else cur = start;                                                            // algo.h:138-140
+                    if (t) cur = walk_move(d, cur, start, wm);                                             // algo.h:134-140
+                    else cur = (uint32_t)d.col[beg0 + (int64_t)(((uint64_t)wm * deg0) >> 32)];            // deg0 > 0 here
                     t++;
                     steps++;
                 }
