@@ -324,8 +324,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     int rc = FORA_OK;
     int L = 0;
     const int nq = d.nq;
-    const unsigned xp = (unsigned)std::min(256, std::max(4, 2048 / std::max(1, nq)));
-    const unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
+    unsigned xp = (unsigned)std::min(256, std::max(4, 2048 / std::max(1, nq)));
+    unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
+    if (const char *e = getenv("FORA_HIP_XP")) if (atoi(e) > 0) xp = (unsigned)atoi(e);
+    if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
     for (;; L++) {
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
         if (c->binned) {

@@ -509,15 +509,24 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
 }
 
 // grid = (X, nq)
+// grid = (X, nq).  A tile is BIN_SPT * BLOCK slices (each lane stages BIN_SPT of them); a chunk is
+// BIN_EPT * BLOCK edges.  Both are sized so that one tile is usually one chunk: the kernel is bound by
+// dependent global round trips (slice load -> gather -> bucket reservation) and block barriers, so more
+// edges per round trip is what raises throughput.
+constexpr int BIN_SPT = 1;
+constexpr uint32_t BIN_TILE = BIN_SPT * BLOCK;
 __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const int q = blockIdx.y;
     const uint32_t nseg = d.segq_count[q * CSTRIDE];
     if (!nseg) return;
-    __shared__ int64_t s_ebeg[BLOCK];
-    __shared__ uint64_t s_inc[BLOCK];
-    __shared__ uint32_t s_pref[BLOCK + 1];
+    __shared__ int64_t s_ebeg[BIN_TILE];
+    __shared__ uint64_t s_inc[BIN_TILE];
+    __shared__ uint32_t s_pref[BIN_TILE + 1];
     __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS];
+    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS], s_lofs[MAX_BINS];
+    // messages of a chunk are staged bin-sorted in LDS and written out in runs: a 4-byte store per edge
+    // straight from the lanes is one L2 write request per ~2 edges (ranks interleave across the bins)
+    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[BLOCK * BIN_EPT];
     const PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
@@ -525,63 +534,81 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
     uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
     if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
-    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nseg; tbase += gridDim.x * BLOCK) {
-        const uint32_t i = tbase + threadIdx.x;
-        uint32_t cnt = 0;
-        if (i < nseg) {
-            const PushSegQ s = segs[i];
-            s_ebeg[threadIdx.x] = s.ebeg;
-            s_inc[threadIdx.x] = s.inc;
-            cnt = s.cnt;
+    for (uint32_t tbase = blockIdx.x * BIN_TILE; tbase < nseg; tbase += gridDim.x * BIN_TILE) {
+        // lane t stages slices t*BIN_SPT .. t*BIN_SPT+BIN_SPT-1 of the tile
+        uint32_t cnt[BIN_SPT], mine = 0;
+#pragma unroll
+        for (int j = 0; j < BIN_SPT; j++) {
+            const uint32_t li = threadIdx.x * BIN_SPT + j;
+            cnt[j] = 0;
+            if (tbase + li < nseg) {
+                const PushSegQ s = segs[tbase + li];
+                s_ebeg[li] = s.ebeg;
+                s_inc[li] = s.inc;
+                cnt[j] = s.cnt;
+            }
+            mine += cnt[j];
         }
         uint32_t total;
-        const uint32_t pre = block_excl_scan(cnt, s_w, total);
-        s_pref[threadIdx.x] = pre;
-        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        uint32_t pre = block_excl_scan(mine, s_w, total);
+#pragma unroll
+        for (int j = 0; j < BIN_SPT; j++) {
+            s_pref[threadIdx.x * BIN_SPT + j] = pre;
+            pre += cnt[j];
+        }
+        if (threadIdx.x == 0) s_pref[BIN_TILE] = total;
         __syncthreads();
         for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
-            // each lane takes BIN_EPT consecutive edges: one binary search, then a linear walk over
-            // the slice boundaries; the lane's loads fall into one or two cache lines
+            // each lane takes BIN_EPT consecutive edges: one binary search, then the slice index advances
+            // by at most one per edge (every slice holds >= 1 edge); all BIN_EPT gathers are issued
+            // before anything waits on them
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
             const uint32_t e0 = cb + threadIdx.x * BIN_EPT;
             uint32_t lo = 0;
             if (e0 < total) {
-                uint32_t hi = BLOCK;
+                uint32_t hi = BIN_TILE;
 #pragma unroll
-                for (int it = 0; it < 8; it++) {
+                for (int it = 0; it < 10; it++) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (s_pref[mid] <= e0) lo = mid; else hi = mid;
+                    if (hi - lo > 1) { if (s_pref[mid] <= e0) lo = mid; else hi = mid; }
                 }
             }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
                 const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
+                si[k] = lo;
                 if (e < total) {
-                    while (s_pref[lo + 1] <= e) lo++;
-                    w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                    lo += s_pref[lo + 1] <= e ? 1u : 0u;
                     si[k] = lo;
-                    rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
+                    w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
                 }
             }
+#pragma unroll
+            for (int k = 0; k < BIN_EPT; k++)
+                if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
             __syncthreads();
-            if (threadIdx.x < (uint32_t)d.nbins) {
-                const uint32_t c = s_cnt[threadIdx.x];
+            if (threadIdx.x < 64) { // wave 0: reserve bucket space and lay the bins out in the LDS stage
+                const uint32_t c = threadIdx.x < (uint32_t)d.nbins ? s_cnt[threadIdx.x] : 0;
+                uint32_t ctot;
+                s_lofs[threadIdx.x] = wave_excl_scan(c, ctot);
                 if (c) {
                     s_base[threadIdx.x] = atomicAdd(&bkc[threadIdx.x * CSTRIDE], c); // ONE global atomic per (chunk, bin)
                     s_cnt[threadIdx.x] = 0;
                 }
             }
             __syncthreads();
+            const uint32_t ctotal = total - cb < BLOCK * BIN_EPT ? total - cb : BLOCK * BIN_EPT;
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
                 bool cross = false;
                 if (w[k] != 0xFFFFFFFFu) {
                     const uint32_t b = w[k] >> BIN_SHIFT;
                     const uint32_t pos = s_base[b] + rank[k];
-                    if (pos < d.bk_cap) {
-                        d.bk_w[bk0 + (uint64_t)b * d.bk_cap + pos] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
-                    } else { // bucket full: fall back to the direct atomic (same result, integer adds commute)
+                    const uint32_t sp = s_lofs[b] + rank[k];
+                    s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
+                    s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
+                    if (pos >= d.bk_cap) { // bucket full: fall back to the direct atomic (same result, integer adds commute)
                         const uint64_t inc = s_inc[si[k]];
                         const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w[k]],
                                                        (unsigned long long)inc);
@@ -590,6 +617,11 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     }
                 }
                 wave_append32(cross, w[k], fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < ctotal; i += BLOCK) { // consecutive lanes -> consecutive bucket slots
+                const uint32_t dst = s_dst[i];
+                if (dst != 0xFFFFFFFFu) d.bk_w[bk0 + dst] = s_msg[i];
             }
         }
         __syncthreads();
