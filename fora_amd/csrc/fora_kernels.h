@@ -122,6 +122,19 @@ __device__ __forceinline__ uint64_t mulshift62(uint64_t r, uint64_t a) {
 }
 __device__ __forceinline__ double fix2d(uint64_t x) { return (double)x * 0x1p-62; }
 
+// exact floor(a / b) for a < 2^63, 1 <= b < 2^32 without the ~150-instruction software 64-bit divide:
+// f64 reciprocal estimate (|error| <= 1536/b + 1), one exact remainder step, +-1 fix-up.
+__device__ __forceinline__ uint64_t div_u64_u32(uint64_t a, uint32_t b) {
+    const double rb = 1.0 / (double)b;
+    const uint64_t q1 = (uint64_t)((double)a * rb);
+    const int64_t r1 = (int64_t)(a - q1 * (uint64_t)b); // |r1| < 2^12 * b: exact in f64
+    int64_t q2 = (int64_t)floor((double)r1 * rb);
+    int64_t r2 = r1 - q2 * (int64_t)b;
+    if (r2 < 0) { q2--; r2 += b; }
+    if (r2 >= (int64_t)b) { q2++; }
+    return q1 + (uint64_t)q2;
+}
+
 // integer form of "residue/outdeg >= rmax" (algo.h:1012); outdeg 0 -> any residue > 0
 __device__ __forceinline__ uint64_t node_thr(uint64_t t1, uint32_t deg) {
     if (deg == 0) return 1;
@@ -293,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) k_push_pop(Dev d, int L) {
                 res_add = keep;
                 dang = push;
             } else {
-                inc = push / deg;                             // algo.h:1002
+                inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg; // algo.h:1002
                 res_add = keep + (push - inc * deg);          // division remainder stays reserved
                 nseg = (uint32_t)((deg + PUSH_SEG - 1) / PUSH_SEG);
             }
@@ -465,7 +478,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
                 res_add = keep;
                 acc_dang += push;
             } else {
-                inc = push / deg;                             // algo.h:1002
+                inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg; // algo.h:1002
                 res_add = keep + (push - inc * deg);
                 nseg = (uint32_t)((deg + PUSH_SEG - 1) / PUSH_SEG);
             }
