@@ -82,9 +82,10 @@ def main():
     from fora_amd.dist import env_world, shard_sources, max_over_ranks, sum_over_ranks
 
     rank, local_rank, world = env_world()
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local_rank)
 
     n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
@@ -110,7 +111,7 @@ def main():
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,14 +125,15 @@ def main():
         last = step()
     fence()
     dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, world, dev)
+    dt = max_over_ranks(dt, world if use_dist else 1, dev)
     tm = eng.timing()
 
     # sanity inside the bench: every query conserved mass exactly, none was skipped
     assert len(last) == len(mine)
     assert all(s["ppr_sum_fix"] == 1 << 62 for s in last), "mass not conserved"
     nd = sum(1 for s in last if not s["dangling_source"])
-    tot = sum_over_ranks([len(mine), nd, tm["walks"], tm["walk_steps"], tm["relax"], tm["pops"]], world, dev)
+    tot = sum_over_ranks([len(mine), nd, tm["walks"], tm["walk_steps"], tm["relax"], tm["pops"]],
+                         world if use_dist else 1, dev)
 
     if rank == 0:
         qps = tot[0] * args.steps / dt
@@ -216,10 +218,10 @@ def main():
             "index_build_s": t_idx,
         }
         print(json.dumps(out))
-    if world > 1:
+    eng.close()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

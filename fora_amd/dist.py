@@ -54,7 +54,8 @@ def gather_topk(ids, scores, total, rank, world, device=None):
 
 
 def max_over_ranks(value, world, device=None):
-    if world == 1:
+    import torch.distributed as _d
+    if world == 1 and not (_d.is_available() and _d.is_initialized()):
         return float(value)
     import torch
     import torch.distributed as dist
@@ -64,7 +65,8 @@ def max_over_ranks(value, world, device=None):
 
 
 def sum_over_ranks(values, world, device=None):
-    if world == 1:
+    import torch.distributed as _d
+    if world == 1 and not (_d.is_available() and _d.is_initialized()):
         return [float(v) for v in values]
     import torch
     import torch.distributed as dist
