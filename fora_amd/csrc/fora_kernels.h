@@ -23,9 +23,12 @@ constexpr uint32_t DEG_SAT = 0xFFFFFFu; // rowinfo low 24 bits: out-degree, satu
 constexpr int MAX_LEVELS = 1 << 15;
 // bucketed push (graphs of up to MAX_BINS * BIN_SIZE nodes): increments are binned by target
 // range and reduced in LDS instead of one global atomic per edge
-constexpr int BIN_SHIFT = 13;
+#ifndef FORA_BIN_SHIFT
+#define FORA_BIN_SHIFT 13
+#endif
+constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
-constexpr int MAX_BINS = 64;
+constexpr int MAX_BINS = 128;
 constexpr int ACC_THREADS = 512;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // push message = (target & (BIN_SIZE-1)) << SEG_BITS | slice index
@@ -601,15 +604,19 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             for (int k = 0; k < BIN_EPT; k++)
                 if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
             __syncthreads();
-            if (threadIdx.x < 64) { // wave 0: reserve bucket space and lay the bins out in the LDS stage
+            if (threadIdx.x < MAX_BINS) { // waves 0-1: reserve bucket space and lay the bins out in the LDS stage
                 const uint32_t c = threadIdx.x < (uint32_t)d.nbins ? s_cnt[threadIdx.x] : 0;
                 uint32_t ctot;
-                s_lofs[threadIdx.x] = wave_excl_scan(c, ctot);
+                const uint32_t pre = wave_excl_scan(c, ctot);
+                if (threadIdx.x == 63) s_w[0] = ctot; // bins 0..63 precede bins 64..127 in the stage
                 if (c) {
                     s_base[threadIdx.x] = atomicAdd(&bkc[threadIdx.x * CSTRIDE], c); // ONE global atomic per (chunk, bin)
                     s_cnt[threadIdx.x] = 0;
                 }
+                s_lofs[threadIdx.x] = pre;
             }
+            __syncthreads();
+            if (threadIdx.x >= 64 && threadIdx.x < MAX_BINS) s_lofs[threadIdx.x] += s_w[0];
             __syncthreads();
             const uint32_t ctotal = total - cb < BLOCK * BIN_EPT ? total - cb : BLOCK * BIN_EPT;
 #pragma unroll
@@ -1120,6 +1127,7 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
     const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
     st.bcnt[lane] = 0;
+    st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
     uint32_t dst[STAGE / 64], rk[STAGE / 64];
 #pragma unroll
@@ -1132,10 +1140,12 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < d.nbins) {
-        const uint32_t c = st.bcnt[lane];
-        if (c) st.bbase[lane] = atomicAdd(&bkc[lane * CSTRIDE], c);
-    }
+#pragma unroll
+    for (int h = 0; h < MAX_BINS; h += 64)
+        if (lane + h < d.nbins) {
+            const uint32_t c = st.bcnt[lane + h];
+            if (c) st.bbase[lane + h] = atomicAdd(&bkc[(lane + h) * CSTRIDE], c);
+        }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++) {
