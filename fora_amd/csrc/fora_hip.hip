@@ -154,17 +154,28 @@ constexpr int FLC_RING = SPEC + 2;
 static bool want_binned(const fora_ctx *c) {
     const char *e = getenv("FORA_HIP_DIRECT");
     if (e && e[0] == '1') return false;
-    // push messages carry the slice index in SEG_BITS bits
+    return (uint64_t)c->n <= (uint64_t)MAX_BINS_WIDE * BIN_SIZE;
+}
+// narrow layout: <= MAX_BINS bins and the slice index fits the 4-byte push message
+static bool want_wide(const fora_ctx *c) {
+    const char *e = getenv("FORA_HIP_FORCE_WIDE"); // tests: exercise the wide layout on small graphs
+    if (e && e[0] == '1') return true;
     const uint64_t segs = (uint64_t)c->n + (uint64_t)c->nnz / PUSH_SEG + 64;
-    return (uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && segs <= (1ull << SEG_BITS);
+    return !((uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && segs <= (1ull << SEG_BITS));
 }
 static uint32_t want_bk_cap() {
     const char *e = getenv("FORA_HIP_BKCAP");
     if (e && atoi(e) > 0) return (uint32_t)atoi(e);
     return 163840; // walk results: ~omega*rsum/nbins per bucket (ws: ~110 k)
 }
+static uint32_t want_bk_cap_wide() { // push messages only (walk results go by direct atomics in the wide layout)
+    const char *e = getenv("FORA_HIP_BKCAP");
+    if (e && atoi(e) > 0) return (uint32_t)atoi(e);
+    return 65536;
+}
 
 struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
+// (the wide / narrow choice changes bk_cap, which forces a re-plan of the workspace)
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     WsPlan p{};
     const uint64_t n = (uint64_t)c->n;
@@ -175,7 +186,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
-        p.bk_cap = want_bk_cap();
+        p.bk_cap = want_wide(c) ? want_bk_cap_wide() : want_bk_cap();
         p.segq_cap = p.segs;
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * (sizeof(PushSegQ) + 8) + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
@@ -260,7 +271,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.alpha32 = (uint32_t)(c->alpha * 4294967296.0);
     d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
     d.alpha = c->alpha; d.omega = omega; d.opt = c->opt;
-    d.binned = c->binned ? 1 : 0; d.nbins = c->nbins;
+    d.binned = c->binned ? 1 : 0; d.nbins = c->nbins; d.wide = c->binned && want_wide(c) ? 1 : 0;
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
     d.segq = c->d_segq; d.inc_tab = c->d_inc_tab; d.segq_count = c->d_segq_count; d.segq_cap = c->segq_cap;
@@ -335,7 +346,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
             hipLaunchKernelGGL(k_pushq_pop, dim3(xp, nq), dim3(BLOCK), 0, c->stream, d, L);
             ev_end(c, h);
             h = ev_begin(c, 1);
-            hipLaunchKernelGGL(k_pushq_bin, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
+            if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
+            else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
             ev_end(c, h);
             h = ev_begin(c, 6);
             hipLaunchKernelGGL(k_accum<false>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
@@ -430,7 +442,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
         hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d, 0u,
                            c->opt ? 1 : 0, (int32_t *)nullptr);
         ev_end(c, h);
-        if (c->binned) {
+        if (c->binned && !d.wide) {
             h = ev_begin(c, 7);
             hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
             ev_end(c, h);
@@ -986,7 +998,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw,
                                (uint32_t)round, with_idx ? 1 : 0, (int32_t *)nullptr);
             ev_end(c, h);
-            if (c->binned) {
+            if (c->binned && !dw.wide) {
                 h = ev_begin(c, 7);
                 hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nb), dim3(ACC_THREADS), 0, c->stream, dw, 0);
                 ev_end(c, h);

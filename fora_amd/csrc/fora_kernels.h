@@ -28,7 +28,8 @@ constexpr int MAX_LEVELS = 1 << 15;
 #endif
 constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
-constexpr int MAX_BINS = 128;
+constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
+constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-B push messages (target, increment)
 constexpr int ACC_THREADS = 512;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // push message = (target & (BIN_SIZE-1)) << SEG_BITS | slice index
@@ -117,6 +118,7 @@ struct Dev {
     uint64_t *bk_inc;       // [slot][bin][bk_cap] its value
     uint32_t *bk_count;     // [slot][bin]
     uint32_t bk_cap;
+    int32_t wide;           // != 0: nbins > MAX_BINS, push messages are (bk_w = local target, bk_inc = increment)
 };
 
 // ------------------------------------------------------------------ helpers
@@ -531,25 +533,28 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
 // edges per round trip is what raises throughput.
 constexpr int BIN_SPT = 1;
 constexpr uint32_t BIN_TILE = BIN_SPT * BLOCK;
+template <int NB>
 __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const int q = blockIdx.y;
     const uint32_t nseg = d.segq_count[q * CSTRIDE];
     if (!nseg) return;
+    constexpr bool WIDE = NB > MAX_BINS;
     __shared__ int64_t s_ebeg[BIN_TILE];
     __shared__ uint64_t s_inc[BIN_TILE];
     __shared__ uint32_t s_pref[BIN_TILE + 1];
     __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_cnt[MAX_BINS], s_base[MAX_BINS], s_lofs[MAX_BINS];
+    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
     // messages of a chunk are staged bin-sorted in LDS and written out in runs: a 4-byte store per edge
     // straight from the lanes is one L2 write request per ~2 edges (ranks interleave across the bins)
     __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[BLOCK * BIN_EPT];
+    __shared__ uint32_t s_sidx[WIDE ? BLOCK * BIN_EPT : 1]; // wide: slice of each staged message (its increment)
     const PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
     const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
     uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
     uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
-    if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     for (uint32_t tbase = blockIdx.x * BIN_TILE; tbase < nseg; tbase += gridDim.x * BIN_TILE) {
         // lane t stages slices t*BIN_SPT .. t*BIN_SPT+BIN_SPT-1 of the tile
         uint32_t cnt[BIN_SPT], mine = 0;
@@ -604,19 +609,31 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             for (int k = 0; k < BIN_EPT; k++)
                 if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
             __syncthreads();
-            if (threadIdx.x < MAX_BINS) { // waves 0-1: reserve bucket space and lay the bins out in the LDS stage
-                const uint32_t c = threadIdx.x < (uint32_t)d.nbins ? s_cnt[threadIdx.x] : 0;
-                uint32_t ctot;
-                const uint32_t pre = wave_excl_scan(c, ctot);
-                if (threadIdx.x == 63) s_w[0] = ctot; // bins 0..63 precede bins 64..127 in the stage
-                if (c) {
-                    s_base[threadIdx.x] = atomicAdd(&bkc[threadIdx.x * CSTRIDE], c); // ONE global atomic per (chunk, bin)
-                    s_cnt[threadIdx.x] = 0;
+            { // reserve bucket space (ONE global atomic per (chunk, bin)) and lay the bins out in the LDS stage:
+              // lane t owns bins t*PER .. t*PER+PER-1
+                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+                uint32_t c[PER], mine = 0;
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t b = threadIdx.x * PER + j;
+                    c[j] = b < (uint32_t)d.nbins && b < (uint32_t)NB ? s_cnt[b] : 0;
+                    mine += c[j];
                 }
-                s_lofs[threadIdx.x] = pre;
+                uint32_t ctot;
+                uint32_t pre = block_excl_scan(mine, s_w, ctot);
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t b = threadIdx.x * PER + j;
+                    if (b < (uint32_t)NB) {
+                        s_lofs[b] = pre;
+                        pre += c[j];
+                        if (c[j]) {
+                            s_base[b] = atomicAdd(&bkc[b * CSTRIDE], c[j]);
+                            s_cnt[b] = 0;
+                        }
+                    }
+                }
             }
-            __syncthreads();
-            if (threadIdx.x >= 64 && threadIdx.x < MAX_BINS) s_lofs[threadIdx.x] += s_w[0];
             __syncthreads();
             const uint32_t ctotal = total - cb < BLOCK * BIN_EPT ? total - cb : BLOCK * BIN_EPT;
 #pragma unroll
@@ -626,7 +643,8 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     const uint32_t b = w[k] >> BIN_SHIFT;
                     const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
+                    if (WIDE) { s_msg[sp] = w[k] & (BIN_SIZE - 1); s_sidx[sp] = si[k]; }
+                    else s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
                     s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
                     if (pos >= d.bk_cap) { // bucket full: fall back to the direct atomic (same result, integer adds commute)
                         const uint64_t inc = s_inc[si[k]];
@@ -641,7 +659,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < ctotal; i += BLOCK) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t dst = s_dst[i];
-                if (dst != 0xFFFFFFFFu) d.bk_w[bk0 + dst] = s_msg[i];
+                if (dst != 0xFFFFFFFFu) {
+                    d.bk_w[bk0 + dst] = s_msg[i];
+                    if (WIDE) d.bk_inc[bk0 + dst] = s_inc[s_sidx[i]];
+                }
             }
         }
         __syncthreads();
@@ -680,6 +701,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         if (threadIdx.x < cnt) {
             w = d.bk_w[bk0 + threadIdx.x];
             if (TO_PPR) inc = d.bk_inc[bk0 + threadIdx.x];
+            else if (d.wide) { inc = d.bk_inc[bk0 + threadIdx.x]; w = node0 + w; }
             else {
                 inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
                 w = node0 + (w >> SEG_BITS);
@@ -710,10 +732,10 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
             mw[k] = 0;
             if (i < cnt) {
                 mw[k] = d.bk_w[bk0 + i];
-                if (TO_PPR) mi[k] = d.bk_inc[bk0 + i];
+                if (TO_PPR || d.wide) mi[k] = d.bk_inc[bk0 + i];
             }
         }
-        if (!TO_PPR) { // push message: target (BIN_SHIFT bits) | slice index (SEG_BITS bits)
+        if (!TO_PPR && !d.wide) { // push message: target (BIN_SHIFT bits) | slice index (SEG_BITS bits)
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
@@ -1226,12 +1248,12 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                 dest = (uint32_t)d.rw_idx[s_pos[lo] + jj];          // query.h:292
                 wgt = s_incr[lo] + (j < s_rem[lo] ? 1 : 0);         // query.h:293
             }
-            if (d.binned) stage_emit(d, q, st, has, dest, wgt);
+            if (d.binned && !d.wide) stage_emit(d, q, st, has, dest, wgt);
             else if (has) atomicAdd((unsigned long long *)&d.ppr[slab + dest], (unsigned long long)wgt);
         }
         __syncthreads();
     }
-    if (d.binned && st.count) stage_flush(d, q, st);
+    if (d.binned && !d.wide && st.count) stage_flush(d, q, st);
 }
 
 // ---- online walks (query.h:297-300, 320-323; build.h:344-354).  grid = (X, nq).
@@ -1253,7 +1275,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, in
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t steps = 0;
     WAVE_STAGE_DECL(st)
-    const bool staged = MODE == WALK_TO_PPR && d.binned;
+    const bool staged = MODE == WALK_TO_PPR && d.binned && !d.wide;
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;

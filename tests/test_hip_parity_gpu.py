@@ -243,7 +243,7 @@ def test_topk_argument_checks(engine, oracle, tiny):
         engine.topk(np.array([1], dtype=np.int32), 10, epsilon=0.5, with_idx=True)
 
 
-@pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow"])
+@pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow"])
 def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
     """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
     overflow fallback all give the twin's bits (integer adds commute)."""
@@ -252,6 +252,11 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         monkeypatch.setenv("FORA_HIP_DIRECT", "1")
     elif mode == "bucketed_overflow":
         monkeypatch.setenv("FORA_HIP_BKCAP", "96")
+    elif mode == "bucketed_wide":
+        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
+    elif mode == "bucketed_wide_overflow":
+        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
+        monkeypatch.setenv("FORA_HIP_BKCAP", "200")
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = np.concatenate([pick_sources(g, 7, 51), pick_sources(g, 1, 52, want_dangling=True)])
     ppr, res, st = engine.query_fix(srcs)
@@ -261,6 +266,7 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["levels"] == wst["levels"]
     monkeypatch.delenv("FORA_HIP_DIRECT", raising=False)
     monkeypatch.delenv("FORA_HIP_BKCAP", raising=False)
+    monkeypatch.delenv("FORA_HIP_FORCE_WIDE", raising=False)
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
