@@ -171,7 +171,7 @@ static uint32_t want_bk_cap() {
 static uint32_t want_bk_cap_wide() { // push messages only (walk results go by direct atomics in the wide layout)
     const char *e = getenv("FORA_HIP_BKCAP");
     if (e && atoi(e) > 0) return (uint32_t)atoi(e);
-    return 65536;
+    return 196608; // also holds the indexed walk results (~omega*rsum/nbins per bucket)
 }
 
 struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
@@ -438,11 +438,15 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
                            (const uint8_t *)nullptr, (uint64_t *)nullptr);
         ev_end(c, h);
         h = ev_begin(c, 3);
-        if (with_idx) hipLaunchKernelGGL(k_walk_idx, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
+        if (with_idx) {
+            if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
+            else if (d.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
+            else hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
+        }
         hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d, 0u,
                            c->opt ? 1 : 0, (int32_t *)nullptr);
         ev_end(c, h);
-        if (c->binned && !d.wide) {
+        if (c->binned && (!d.wide || with_idx)) {
             h = ev_begin(c, 7);
             hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
             ev_end(c, h);
@@ -994,11 +998,15 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
                                (const uint8_t *)c->d_active, c->d_cursor);
             ev_end(c, h);
             h = ev_begin(c, 3);
-            if (with_idx) hipLaunchKernelGGL(k_walk_idx, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
+            if (with_idx) {
+                if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
+                else if (dw.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
+                else hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
+            }
             hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw,
                                (uint32_t)round, with_idx ? 1 : 0, (int32_t *)nullptr);
             ev_end(c, h);
-            if (c->binned && !dw.wide) {
+            if (c->binned && (!dw.wide || with_idx)) {
                 h = ev_begin(c, 7);
                 hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nb), dim3(ACC_THREADS), 0, c->stream, dw, 0);
                 ev_end(c, h);

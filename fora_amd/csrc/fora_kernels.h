@@ -1207,16 +1207,26 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
     st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6]; st.count = 0;
 
 // ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
-// are read from rw_idx.  Streaming gather; grid = (X, nq).
+// are read from rw_idx.  Streaming gather; grid = (X, nq).  With the bucketed layouts the results
+// go through the same block-level chunk binning as the push (LDS histogram, one global atomic per
+// (chunk, bin), bin-sorted LDS stage, run write-out) and are reduced by k_accum<true>.
+template <int NB>
 __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
+    constexpr int EPT = BIN_EPT;
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_pref[BLOCK + 1], s_w[4];
+    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_msg[NB > 1 ? BLOCK * EPT : 1], s_dst[NB > 1 ? BLOCK * EPT : 1];
+    __shared__ uint64_t s_val[NB > 1 ? BLOCK * EPT : 1];
+    constexpr bool BINNED = NB > 1;
     const int q = blockIdx.y;
     const uint32_t nitems = d.wit_count[q * CSTRIDE];
     if (!nitems) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
-    WAVE_STAGE_DECL(st)
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
@@ -1231,29 +1241,99 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
         s_pref[threadIdx.x] = pre;
         if (threadIdx.x == 0) s_pref[BLOCK] = total;
         __syncthreads();
-        for (uint32_t eb = 0; eb < total; eb += BLOCK) {
-            const uint32_t e = eb + threadIdx.x;
-            const bool has = e < total;
-            uint32_t dest = 0;
-            uint64_t wgt = 0;
-            if (has) {
-                uint32_t lo = 0, hi = BLOCK;
+        for (uint32_t cb = 0; cb < total; cb += BLOCK * EPT) {
+            uint32_t dest[EPT], rank[EPT];
+            uint64_t wgt[EPT];
+            const uint32_t e0 = cb + threadIdx.x * EPT;
+            uint32_t lo = 0;
+            if (e0 < total) {
+                uint32_t hi = BLOCK;
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                    if (s_pref[mid] <= e0) lo = mid; else hi = mid;
                 }
-                const uint32_t jj = e - s_pref[lo];
-                const uint64_t j = s_j0[lo] + jj;
-                dest = (uint32_t)d.rw_idx[s_pos[lo] + jj];          // query.h:292
-                wgt = s_incr[lo] + (j < s_rem[lo] ? 1 : 0);         // query.h:293
             }
-            if (d.binned && !d.wide) stage_emit(d, q, st, has, dest, wgt);
-            else if (has) atomicAdd((unsigned long long *)&d.ppr[slab + dest], (unsigned long long)wgt);
+            uint32_t li[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; k++) { // items can be empty here (idx_n == 0): advance past them
+                const uint32_t e = e0 + k;
+                if (e < total) while (s_pref[lo + 1] <= e) lo++;
+                li[k] = lo;
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; k++) { // straight-line: all EPT gathers in flight together
+                const uint32_t e = e0 + k;
+                dest[k] = 0xFFFFFFFFu;
+                wgt[k] = 0;
+                if (e < total) {
+                    const uint32_t jj = e - s_pref[li[k]];
+                    const uint64_t j = s_j0[li[k]] + jj;
+                    dest[k] = (uint32_t)d.rw_idx[s_pos[li[k]] + jj];    // query.h:292
+                    wgt[k] = s_incr[li[k]] + (j < s_rem[li[k]] ? 1 : 0); // query.h:293
+                }
+            }
+            if (!BINNED) {
+#pragma unroll
+                for (int k = 0; k < EPT; k++)
+                    if (dest[k] != 0xFFFFFFFFu)
+                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+                if (dest[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[dest[k] >> BIN_SHIFT], 1u);
+            __syncthreads();
+            {
+                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+                uint32_t c[PER], mine = 0;
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t b = threadIdx.x * PER + j;
+                    c[j] = b < (uint32_t)d.nbins && b < (uint32_t)NB ? s_cnt[b] : 0;
+                    mine += c[j];
+                }
+                uint32_t ctot;
+                uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t b = threadIdx.x * PER + j;
+                    if (b < (uint32_t)NB) {
+                        s_lofs[b] = pre2;
+                        pre2 += c[j];
+                        if (c[j]) {
+                            s_base[b] = atomicAdd(&bkc[b * CSTRIDE], c[j]); // ONE global atomic per (chunk, bin)
+                            s_cnt[b] = 0;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t ctotal = total - cb < BLOCK * EPT ? total - cb : BLOCK * EPT;
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                if (dest[k] != 0xFFFFFFFFu) {
+                    const uint32_t b = dest[k] >> BIN_SHIFT;
+                    const uint32_t pos = s_base[b] + rank[k];
+                    const uint32_t sp = s_lofs[b] + rank[k];
+                    s_msg[sp] = dest[k];
+                    s_val[sp] = wgt[k];
+                    s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
+                    if (pos >= d.bk_cap) // bucket full: direct atomic, same sum
+                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
+                }
+            }
+            __syncthreads();
+            for (uint32_t m = threadIdx.x; m < ctotal; m += BLOCK) {
+                const uint32_t dst = s_dst[m];
+                if (dst != 0xFFFFFFFFu) {
+                    d.bk_w[bk0 + dst] = s_msg[m];
+                    d.bk_inc[bk0 + dst] = s_val[m];
+                }
+            }
         }
         __syncthreads();
     }
-    if (d.binned && !d.wide && st.count) stage_flush(d, q, st);
 }
 
 // ---- online walks (query.h:297-300, 320-323; build.h:344-354).  grid = (X, nq).
