@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="queries in flight per launch (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--topk", type=int, default=0, help="k > 0: time `topk --opt` (config 5 style) instead of `query`")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-kernel FETCH_SIZE/WRITE_SIZE summary from separate rocprofv3 --pmc passes (tools/pmc_summary.py)")
     return ap.parse_args()
@@ -92,7 +93,7 @@ def main():
     eng = fora_amd.Engine(local_rank)
     arch, cus, hbm = eng.device_info()
     eng.set_graph(n, m, row_ptr, col)
-    eng.set_params(alpha=0.2, epsilon=args.epsilon, opt=args.opt, seed=0x464F5241)
+    eng.set_params(alpha=0.2, epsilon=args.epsilon, opt=args.opt or bool(args.topk), seed=0x464F5241)
     rmax, omega = eng.get_params()
     if args.batch:
         eng.set_batch(args.batch)
@@ -106,7 +107,13 @@ def main():
     all_sources = synth.query_set(n, args.queries * world, 20261001)
     mine = shard_sources(all_sources, rank, world)
 
+    topk_out = {}
+
     def step():
+        if args.topk:
+            ids, sc, rounds = eng.topk(mine, args.topk, epsilon=args.epsilon, with_idx=args.with_idx)
+            topk_out["ids"], topk_out["sc"], topk_out["rounds"] = ids, sc, rounds
+            return None
         _, st = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
         return st
 
@@ -128,6 +135,28 @@ def main():
     dt = max_over_ranks(dt, world if use_dist else 1, dev)
     tm = eng.timing()
 
+    if args.topk:
+        # top-k: gather the per-rank lists (RCCL all-gather when distributed), check they are sorted
+        from fora_amd.dist import gather_topk
+        g_ids, g_sc = gather_topk(topk_out["ids"], topk_out["sc"], len(mine) * world, rank, world if use_dist else 1,
+                                  dev if use_dist else None)
+        assert (np.diff(g_sc, axis=1) <= 0).all()
+        if rank == 0:
+            dtq = dt
+            print(json.dumps({
+                "metric": "SSPPR top-k queries/sec at eps=0.5", "value": len(mine) * world * args.steps / dtq,
+                "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dtq / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u64 fixed-point 2^-62 (f64 at the boundary)", "data": "synthetic",
+                "config": {"workload": f"{args.graph}-sized R-MAT topk k={args.topk} --opt"
+                                       f"{' --with_idx' if args.with_idx else ''} query_size={args.queries}/GPU on {world}x MI355X",
+                           "k": args.topk, "avg_rounds": float(np.mean(topk_out["rounds"])), "batch": eng.get_batch()},
+                "phases": {k: v for k, v in tm.items() if k.endswith("_ms")}}))
+        eng.close()
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # sanity inside the bench: every query conserved mass exactly, none was skipped
     assert len(last) == len(mine)
     assert all(s["ppr_sum_fix"] == 1 << 62 for s in last), "mass not conserved"
