@@ -214,10 +214,11 @@ def main():
                 # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
                 # coalesced reads by up to 2x on gfx950 -- these kernels read 4-12 B per lane, reported raw)
                 pmc = json.load(open(args.traffic))
-                names = ["fora::k_pushq_bin", "fora::k_accum<false>"] if bucketed else ["fora::k_push_expand"]
-                if all(k in pmc for k in names):
+                prefixes = ["fora::k_pushq_bin", "fora::k_accum<false>"] if bucketed else ["fora::k_push_expand"]
+                keys = [[k for k in pmc if k.startswith(p)] for p in prefixes]
+                if all(keys):
                     traffic = sum(pmc[k].get("FETCH_SIZE_bytes_per_launch", 0) + pmc[k].get("WRITE_SIZE_bytes_per_launch", 0)
-                                  for k in names)
+                                  for ks in keys for k in ks)
                     traffic_note = pmc.get("_note")
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
