@@ -67,9 +67,11 @@ struct fora_ctx {
     bool binned = false;
     int nbins = 0;
     uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
-    PushSegQ *d_segq = nullptr;
     uint64_t *d_inc_tab = nullptr;
-    uint32_t *d_segq_count = nullptr, *d_bk_w = nullptr, *d_bk_count = nullptr;
+    uint32_t *d_ov_w = nullptr, *d_ov_count = nullptr; // bucket overflow list
+    uint64_t *d_ov_inc = nullptr;
+    uint32_t ov_cap = 0;
+    uint32_t *d_bk_w = nullptr, *d_bk_count = nullptr;
     uint64_t *d_bk_inc = nullptr;
     uint64_t segq_cap = 0;
     uint32_t bk_cap = 0;
@@ -132,7 +134,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     c->topk_cap = 0;
-    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_segq); dfree(c->d_inc_tab); dfree(c->d_segq_count);
+    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
@@ -160,8 +162,7 @@ static bool want_binned(const fora_ctx *c) {
 static bool want_wide(const fora_ctx *c) {
     const char *e = getenv("FORA_HIP_FORCE_WIDE"); // tests: exercise the wide layout on small graphs
     if (e && e[0] == '1') return true;
-    const uint64_t segs = (uint64_t)c->n + (uint64_t)c->nnz / PUSH_SEG + 64;
-    return !((uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && segs <= (1ull << SEG_BITS));
+    return !((uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && (uint64_t)c->n <= (1ull << SEG_BITS));
 }
 static uint32_t want_bk_cap() {
     const char *e = getenv("FORA_HIP_BKCAP");
@@ -187,9 +188,9 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
         p.bk_cap = want_wide(c) ? want_bk_cap_wide() : want_bk_cap();
-        p.segq_cap = p.segs;
+        p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * (sizeof(PushSegQ) + 8) + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + 262144ull * 12 + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -220,9 +221,11 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_fl[0], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl[1], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
-        HIPCHK(c, hipMalloc(&c->d_segq, (uint64_t)B * p.segq_cap * sizeof(PushSegQ)));
         HIPCHK(c, hipMalloc(&c->d_inc_tab, (uint64_t)B * p.segq_cap * 8));
-        HIPCHK(c, hipMalloc(&c->d_segq_count, (size_t)B * 4 * CSTRIDE));
+        c->ov_cap = 262144;
+        HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
+        HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
         HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.nbins * p.bk_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.nbins * p.bk_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.nbins * 4 * CSTRIDE));
@@ -274,7 +277,9 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.binned = c->binned ? 1 : 0; d.nbins = c->nbins; d.wide = c->binned && want_wide(c) ? 1 : 0;
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
-    d.segq = c->d_segq; d.inc_tab = c->d_inc_tab; d.segq_count = c->d_segq_count; d.segq_cap = c->segq_cap;
+    d.inc_tab = c->d_inc_tab; d.segq_cap = c->segq_cap;
+    d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
+    d.ov_count[0] = c->d_ov_count; d.ov_count[1] = c->d_ov_count ? c->d_ov_count + (size_t)c->B * CSTRIDE : nullptr;
     d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;
@@ -320,7 +325,8 @@ int check_dev_err(fora_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (e) {
         char buf[96];
-        snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x)", e);
+        snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x%s)", e,
+                 (e & ERR_BUCKET_OVERFLOW) ? ": message buckets and their overflow list are full, raise FORA_HIP_BKCAP" : "");
         return fail(c, FORA_E_OVERFLOW, buf);
     }
     return FORA_OK;
@@ -335,19 +341,14 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     int rc = FORA_OK;
     int L = 0;
     const int nq = d.nq;
-    unsigned xp = (unsigned)std::min(256, std::max(4, 2048 / std::max(1, nq)));
     unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
-    if (const char *e = getenv("FORA_HIP_XP")) if (atoi(e) > 0) xp = (unsigned)atoi(e);
     if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
     for (;; L++) {
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
         if (c->binned) {
-            int h = ev_begin(c, 0);
-            hipLaunchKernelGGL(k_pushq_pop, dim3(xp, nq), dim3(BLOCK), 0, c->stream, d, L);
-            ev_end(c, h);
-            h = ev_begin(c, 1);
-            if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
-            else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
+            int h = ev_begin(c, 1);
+            if (d.wide) hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
+            else hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
             ev_end(c, h);
             h = ev_begin(c, 6);
             hipLaunchKernelGGL(k_accum<false>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
@@ -395,8 +396,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
 int reset_binned_counters(fora_ctx *c) {
     if (!c->binned) return FORA_OK;
     HIPCHK(c, hipMemsetAsync(c->d_fl_count, 0, (size_t)c->B * 2 * 4 * CSTRIDE, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_segq_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->nbins * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
     return FORA_OK;
 }
 

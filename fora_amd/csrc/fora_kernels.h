@@ -32,18 +32,11 @@ constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged 
 constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-B push messages (target, increment)
 constexpr int ACC_THREADS = 512;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
-constexpr int SEG_BITS = 32 - BIN_SHIFT; // push message = (target & (BIN_SIZE-1)) << SEG_BITS | slice index
+constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
 
 // error flag bits (Dev::err)
-constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4;
-
-struct PushSegQ {     // bucketed push: slice of a popped node's out-edges (slot is implicit)
-    int64_t ebeg;
-    uint64_t inc;
-    uint32_t cnt;
-    uint32_t pad;
-};
+constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4, ERR_BUCKET_OVERFLOW = 8;
 
 struct PushSeg {      // one <=PUSH_SEG-edge slice of a popped node's out-edges
     int64_t ebeg;     // first edge (index into col)
@@ -110,14 +103,18 @@ struct Dev {
     int32_t binned, nbins;
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
-    PushSegQ *segq;         // [slot][segq_cap]
-    uint64_t *inc_tab;      // [slot][segq_cap] increment of slice i (compact: gathered by k_accum)
-    uint32_t *segq_count;   // [slot]
-    uint64_t segq_cap;
+    uint64_t *inc_tab;      // [slot][segq_cap] increment of the node at frontier position i (gathered by k_accum)
+    uint64_t segq_cap;      // = n: a frontier holds each node at most once
     uint32_t *bk_w;         // [slot][bin][bk_cap] target node of a pending increment
     uint64_t *bk_inc;       // [slot][bin][bk_cap] its value
     uint32_t *bk_count;     // [slot][bin]
     uint32_t bk_cap;
+    // messages that found their bucket full (rare; capacity is a tuning knob): per-slot overflow list,
+    // folded in by k_accum.  Count is double-buffered by level parity (zeroed one level later).
+    uint32_t *ov_w;         // [slot][ov_cap]
+    uint64_t *ov_inc;       // [slot][ov_cap]
+    uint32_t *ov_count[2];  // [slot * CSTRIDE]
+    uint32_t ov_cap;
     int32_t wide;           // != 0: nbins > MAX_BINS, push messages are (bk_w = local target, bk_inc = increment)
 };
 
@@ -453,157 +450,99 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 //                  workgroup owns that residue range), threshold crossing -> next frontier
 // Integer adds commute, so the result is bit-identical to the direct path and to the twin.
 
-// grid = (X, nq)
-__global__ void __launch_bounds__(BLOCK) k_pushq_pop(Dev d, int L) {
+// grid = (X, nq).  Fused pop + bin: a block takes 256 frontier nodes of a slot, pops them (residue ->
+// reserve, increment; algo.h:983-1002) straight into LDS, then bins their concatenated out-edges in
+// chunks of BIN_EPT * BLOCK: each lane gathers BIN_EPT consecutive edges (all loads issued before any
+// is waited for), an LDS histogram over the target bins gives every message its rank, ONE global
+// atomic per (chunk, bin) reserves bucket space, and the messages are staged bin-sorted in LDS and
+// written out in runs.  No slice list is materialised: a narrow message names the frontier position of
+// its source node (increment table `inc_tab`), a wide one carries the increment.
+template <int NB>
+__global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     const int q = blockIdx.y;
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
+        d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
+    }
     if (!count) return;
+    constexpr bool WIDE = NB > MAX_BINS;
+    __shared__ int64_t s_ebeg[BLOCK];
+    __shared__ uint64_t s_inc[BLOCK];
+    __shared__ uint32_t s_pref[BLOCK + 1];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[BLOCK * BIN_EPT];
+    __shared__ uint32_t s_sidx[WIDE ? BLOCK * BIN_EPT : 1]; // wide: source of each staged message (its increment)
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t *in = d.fl[par] + slab;
-    PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
+    uint64_t *incs = d.inc_tab + (uint64_t)q * d.segq_cap;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
-    for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        uint32_t nseg = 0;
-        uint64_t inc = 0, deg = 0;
-        int64_t beg = 0;
+    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < count; tbase += gridDim.x * BLOCK) {
+        // ---- pop: one frontier node per lane
+        const uint32_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
         if (i < count) {
             const uint32_t v = in[i];
             const uint64_t a = slab + v;
             const uint64_t r = d.residue[a];
+            int64_t beg; uint64_t deg;
+            node_row(d, v, beg, deg);
+            const uint64_t reserve_old = d.ppr[a];
             d.residue[a] = 0;                                 // algo.h:985
             const uint64_t keep = mulshift62(r, d.afix);      // v_residue * alpha
             const uint64_t push = r - keep;                   // (1-alpha) * v_residue
-            node_row(d, v, beg, deg);
-            uint64_t res_add;
+            uint64_t inc = 0, res_add;
             if (deg == 0) {                                   // algo.h:993-994
                 res_add = keep;
                 acc_dang += push;
             } else {
                 inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg; // algo.h:1002
-                res_add = keep + (push - inc * deg);
-                nseg = (uint32_t)((deg + PUSH_SEG - 1) / PUSH_SEG);
+                res_add = keep + (push - inc * deg);          // division remainder stays reserved
             }
-            d.ppr[a] += res_add;                              // algo.h:986-989
+            d.ppr[a] = reserve_old + res_add;                 // algo.h:986-989 (only this lane owns (q,v))
             acc_res += res_add;
             acc_pops++;
             acc_relax += deg;
-        }
-        uint32_t tot;
-        const uint32_t off = wave_excl_scan(nseg, tot);
-        if (tot) {
-            uint32_t sb = 0;
-            if (lane == 0) sb = atomicAdd(&d.segq_count[q * CSTRIDE], tot);
-            sb = __shfl(sb, 0);
-            if ((uint64_t)sb + tot > d.segq_cap) {
-                if (lane == 0) atomicOr(d.err, ERR_SEG_OVERFLOW);
-            } else {
-                for (uint32_t k = 0; k < nseg; k++) {
-                    PushSegQ s;
-                    s.ebeg = beg + (int64_t)k * PUSH_SEG;
-                    s.inc = inc;
-                    const uint64_t left = deg - (uint64_t)k * PUSH_SEG;
-                    s.cnt = left < PUSH_SEG ? (uint32_t)left : PUSH_SEG;
-                    s.pad = 0;
-                    segs[sb + off + k] = s;
-                    d.inc_tab[(uint64_t)q * d.segq_cap + sb + off + k] = inc;
-                }
-            }
-        }
-    }
-    acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
-    acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
-    if (lane == 0 && acc_pops) {
-        QState *s = &d.qs[q];
-        atomicAdd(&s->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
-        if (acc_dang) atomicAdd(&s->dang, (unsigned long long)acc_dang);
-        atomicAdd(&s->pops, (unsigned long long)acc_pops);
-        if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
-        s->levels = (uint32_t)L + 1;
-    }
-}
-
-// grid = (X, nq)
-// grid = (X, nq).  A tile is BIN_SPT * BLOCK slices (each lane stages BIN_SPT of them); a chunk is
-// BIN_EPT * BLOCK edges.  Both are sized so that one tile is usually one chunk: the kernel is bound by
-// dependent global round trips (slice load -> gather -> bucket reservation) and block barriers, so more
-// edges per round trip is what raises throughput.
-constexpr int BIN_SPT = 1;
-constexpr uint32_t BIN_TILE = BIN_SPT * BLOCK;
-template <int NB>
-__global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
-    const int q = blockIdx.y;
-    const uint32_t nseg = d.segq_count[q * CSTRIDE];
-    if (!nseg) return;
-    constexpr bool WIDE = NB > MAX_BINS;
-    __shared__ int64_t s_ebeg[BIN_TILE];
-    __shared__ uint64_t s_inc[BIN_TILE];
-    __shared__ uint32_t s_pref[BIN_TILE + 1];
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    // messages of a chunk are staged bin-sorted in LDS and written out in runs: a 4-byte store per edge
-    // straight from the lanes is one L2 write request per ~2 edges (ranks interleave across the bins)
-    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[BLOCK * BIN_EPT];
-    __shared__ uint32_t s_sidx[WIDE ? BLOCK * BIN_EPT : 1]; // wide: slice of each staged message (its increment)
-    const PushSegQ *segs = d.segq + (uint64_t)q * d.segq_cap;
-    const uint64_t slab = (uint64_t)q * d.n;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
-    uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
-    uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
-    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
-    for (uint32_t tbase = blockIdx.x * BIN_TILE; tbase < nseg; tbase += gridDim.x * BIN_TILE) {
-        // lane t stages slices t*BIN_SPT .. t*BIN_SPT+BIN_SPT-1 of the tile
-        uint32_t cnt[BIN_SPT], mine = 0;
-#pragma unroll
-        for (int j = 0; j < BIN_SPT; j++) {
-            const uint32_t li = threadIdx.x * BIN_SPT + j;
-            cnt[j] = 0;
-            if (tbase + li < nseg) {
-                const PushSegQ s = segs[tbase + li];
-                s_ebeg[li] = s.ebeg;
-                s_inc[li] = s.inc;
-                cnt[j] = s.cnt;
-            }
-            mine += cnt[j];
+            s_ebeg[threadIdx.x] = beg;
+            s_inc[threadIdx.x] = inc;
+            if (!WIDE) incs[i] = inc;
+            cnt = (uint32_t)deg;
         }
         uint32_t total;
-        uint32_t pre = block_excl_scan(mine, s_w, total);
-#pragma unroll
-        for (int j = 0; j < BIN_SPT; j++) {
-            s_pref[threadIdx.x * BIN_SPT + j] = pre;
-            pre += cnt[j];
-        }
-        if (threadIdx.x == 0) s_pref[BIN_TILE] = total;
+        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[BLOCK] = total;
         __syncthreads();
+        // ---- bin the tile's edges
         for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
-            // each lane takes BIN_EPT consecutive edges: one binary search, then the slice index advances
-            // by at most one per edge (every slice holds >= 1 edge); all BIN_EPT gathers are issued
-            // before anything waits on them
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
             const uint32_t e0 = cb + threadIdx.x * BIN_EPT;
             uint32_t lo = 0;
             if (e0 < total) {
-                uint32_t hi = BIN_TILE;
+                uint32_t hi = BLOCK;
 #pragma unroll
-                for (int it = 0; it < 10; it++) {
+                for (int it = 0; it < 8; it++) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (hi - lo > 1) { if (s_pref[mid] <= e0) lo = mid; else hi = mid; }
+                    if (s_pref[mid] <= e0) lo = mid; else hi = mid;
                 }
             }
 #pragma unroll
-            for (int k = 0; k < BIN_EPT; k++) {
+            for (int k = 0; k < BIN_EPT; k++) { // dangling nodes own no edges: step over them
+                const uint32_t e = e0 + k;
+                if (e < total) while (s_pref[lo + 1] <= e) lo++;
+                si[k] = lo;
+            }
+#pragma unroll
+            for (int k = 0; k < BIN_EPT; k++) { // straight-line: all BIN_EPT gathers in flight together
                 const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
-                si[k] = lo;
-                if (e < total) {
-                    lo += s_pref[lo + 1] <= e ? 1u : 0u;
-                    si[k] = lo;
-                    w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
-                }
+                if (e < total) w[k] = (uint32_t)d.col[s_ebeg[si[k]] + (e - s_pref[si[k]])];
             }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++)
@@ -620,13 +559,13 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     mine += c[j];
                 }
                 uint32_t ctot;
-                uint32_t pre = block_excl_scan(mine, s_w, ctot);
+                uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
                     if (b < (uint32_t)NB) {
-                        s_lofs[b] = pre;
-                        pre += c[j];
+                        s_lofs[b] = pre2;
+                        pre2 += c[j];
                         if (c[j]) {
                             s_base[b] = atomicAdd(&bkc[b * CSTRIDE], c[j]);
                             s_cnt[b] = 0;
@@ -638,7 +577,6 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             const uint32_t ctotal = total - cb < BLOCK * BIN_EPT ? total - cb : BLOCK * BIN_EPT;
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
-                bool cross = false;
                 if (w[k] != 0xFFFFFFFFu) {
                     const uint32_t b = w[k] >> BIN_SHIFT;
                     const uint32_t pos = s_base[b] + rank[k];
@@ -646,26 +584,35 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     if (WIDE) { s_msg[sp] = w[k] & (BIN_SIZE - 1); s_sidx[sp] = si[k]; }
                     else s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
                     s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
-                    if (pos >= d.bk_cap) { // bucket full: fall back to the direct atomic (same result, integer adds commute)
-                        const uint64_t inc = s_inc[si[k]];
-                        const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w[k]],
-                                                       (unsigned long long)inc);
-                        const uint64_t thr = node_thr(d.t1, d.deg[w[k]]);
-                        cross = old < thr && old + inc >= thr;
+                    if (pos >= d.bk_cap) { // bucket full: park the increment in the slot's overflow list
+                        const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
+                        if (oi < d.ov_cap) {
+                            d.ov_w[(uint64_t)q * d.ov_cap + oi] = w[k];
+                            d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[si[k]];
+                        } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
                     }
                 }
-                wave_append32(cross, w[k], fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < ctotal; i += BLOCK) { // consecutive lanes -> consecutive bucket slots
-                const uint32_t dst = s_dst[i];
+            for (uint32_t m = threadIdx.x; m < ctotal; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
+                const uint32_t dst = s_dst[m];
                 if (dst != 0xFFFFFFFFu) {
-                    d.bk_w[bk0 + dst] = s_msg[i];
-                    if (WIDE) d.bk_inc[bk0 + dst] = s_inc[s_sidx[i]];
+                    d.bk_w[bk0 + dst] = s_msg[m];
+                    if (WIDE) d.bk_inc[bk0 + dst] = s_inc[s_sidx[m]];
                 }
             }
         }
         __syncthreads();
+    }
+    acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
+    acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
+    if (lane == 0 && acc_pops) {
+        QState *s = &d.qs[q];
+        atomicAdd(&s->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
+        if (acc_dang) atomicAdd(&s->dang, (unsigned long long)acc_dang);
+        atomicAdd(&s->pops, (unsigned long long)acc_pops);
+        if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
+        s->levels = (uint32_t)L + 1;
     }
 }
 
@@ -678,22 +625,23 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t bi = (uint32_t)q * d.nbins + b;
     uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
-    if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess went through the direct path
+    if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess is in the overflow list (push) / went by direct atomics (walks)
     const uint32_t s = (uint32_t)d.src[q];
     const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang : 0; // algo.h:994
     uint64_t *target = TO_PPR ? d.ppr : d.residue;
     __syncthreads();
     if (threadIdx.x == 0) {
         d.bk_count[(uint64_t)bi * CSTRIDE] = 0;
-        if (!TO_PPR && b == 0) d.segq_count[q * CSTRIDE] = 0;
         if (dm) d.qs[q].dang = 0;
     }
-    if (cnt == 0 && dm == 0) return;
+    uint32_t ovn = TO_PPR ? 0 : d.ov_count[L & 1][q * CSTRIDE];
+    if (ovn > d.ov_cap) ovn = d.ov_cap;
+    if (cnt == 0 && dm == 0 && ovn == 0) return;
     uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
     uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
     const uint64_t bk0 = (uint64_t)bi * d.bk_cap;
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
-    if (cnt + (dm ? 1 : 0) <= ACC_THREADS / 4) {
+    if (ovn == 0 && cnt + (dm ? 1 : 0) <= ACC_THREADS / 4) {
         // tiny bucket: zeroing and sweeping 64 KiB of LDS would cost more than a few atomics
         bool cross = false;
         uint32_t w = 0;
@@ -748,6 +696,11 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
             if (mi[k]) atomicAdd((unsigned long long *)&acc[mw[k] & (BIN_SIZE - 1)], (unsigned long long)mi[k]);
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
+    for (uint32_t i = threadIdx.x; i < ovn; i += ACC_THREADS) { // increments whose bucket was full
+        const uint32_t w = d.ov_w[(uint64_t)q * d.ov_cap + i];
+        if ((int)(w >> BIN_SHIFT) == b)
+            atomicAdd((unsigned long long *)&acc[w & (BIN_SIZE - 1)], (unsigned long long)d.ov_inc[(uint64_t)q * d.ov_cap + i]);
+    }
     __syncthreads();
     // sweep: consecutive lanes -> consecutive nodes; all loads of a lane's 16 nodes in flight together
     constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
