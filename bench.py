@@ -199,11 +199,13 @@ def main():
         if tm["push_expand_launches"]:
             e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
             p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
-            alg_bytes = 24.0 * e_unit * q_timed
             launches = tm["push_expand_launches"]
             bucketed = tm["push_accum_launches"] > 0
-            # bucketed push: one level's expand step is the kernel PAIR bin + accum (same launch count);
-            # the 24 B/edge are credited once, against the sum of both kernels' durations
+            fused = bucketed and tm["push_pop_launches"] == 0
+            # bucketed push: one level is the kernel PAIR k_pushq_popbin + k_accum<false> (same launch count);
+            # the pop is fused into the first, so the pair carries the whole push: 52 B per pop + 24 B per edge
+            # relaxation of the sequential FIFO oracle, credited once against the sum of both kernels' durations
+            alg_bytes = (24.0 * e_unit + (52.0 * p_unit if fused else 0.0)) * q_timed
             step_ms = tm["push_expand_ms"] + tm["push_accum_ms"]
             avg_ms = step_ms / launches
             achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
@@ -214,22 +216,28 @@ def main():
                 # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
                 # coalesced reads by up to 2x on gfx950 -- these kernels read 4-12 B per lane, reported raw)
                 pmc = json.load(open(args.traffic))
-                prefixes = ["fora::k_pushq_bin", "fora::k_accum<false>"] if bucketed else ["fora::k_push_expand"]
+                prefixes = (["fora::k_pushq_popbin", "fora::k_accum<false>"] if fused else
+                            ["fora::k_pushq_bin", "fora::k_accum<false>"] if bucketed else ["fora::k_push_expand"])
                 keys = [[k for k in pmc if k.startswith(p)] for p in prefixes]
                 if all(keys):
                     traffic = sum(pmc[k].get("FETCH_SIZE_bytes_per_launch", 0) + pmc[k].get("WRITE_SIZE_bytes_per_launch", 0)
                                   for ks in keys for k in ks)
                     traffic_note = pmc.get("_note")
+            by_kernel = {("k_pushq_popbin" if fused else "k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / launches}
+            if bucketed:
+                by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
+            if tm["push_pop_launches"]:
+                by_kernel["k_pushq_pop" if bucketed else "k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": "fora::k_pushq_bin + fora::k_pushq_accum (expand step of one level)" if bucketed
-                          else "fora::k_push_expand",
-                "launches": int(launches), "avg_launch_ms": avg_ms,
-                "avg_ms_by_kernel": {"k_pushq_bin" if bucketed else "k_push_expand": tm["push_expand_ms"] / launches,
-                                     "k_pushq_accum": tm["push_accum_ms"] / max(1, tm["push_accum_launches"]),
-                                     "k_pushq_pop" if bucketed else "k_push_pop": tm["push_pop_ms"] / max(1, tm["push_pop_launches"])},
+                "kernel": ("fora::k_pushq_popbin + fora::k_accum<false> (one level of the push)" if fused else
+                           "fora::k_pushq_bin + fora::k_accum<false> (expand step of one level)" if bucketed
+                           else "fora::k_push_expand"),
+                "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation of the sequential FIFO oracle" if fused
+                                     else "24 B per edge relaxation of the sequential FIFO oracle",
                 "fifo_relaxations_per_query": e_unit, "fifo_pops_per_query": p_unit,
                 "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed),
                 "push_total": {  # all push kernels against 52*P + 24*E

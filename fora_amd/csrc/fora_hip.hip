@@ -259,6 +259,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.n = c->n; d.nq = nq;
     d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col; d.deg = c->d_deg;
     d.rp32 = c->d_rp32; d.colp = c->d_colp; d.colbits = c->colbits;
+    d.colp32 = (uint64_t)c->nnz * c->colbits < (1ull << 32) ? 1 : 0;
     d.residue = c->d_residue; d.ppr = c->d_ppr;
     d.wl[0] = c->d_wl[0]; d.wl[1] = c->d_wl[1]; d.wl_cap = c->wl_cap;
     d.seg = (PushSeg *)c->d_scratch; d.seg_cap = c->seg_cap;

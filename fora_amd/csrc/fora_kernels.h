@@ -77,6 +77,7 @@ struct Dev {
     const uint32_t *rp32;   // [n + 1] or null
     const uint32_t *colp;   // bit-packed column ids, entry e at bit e*colbits, read as two aligned dwords
     uint32_t colbits;
+    uint32_t colp32;        // != 0: bit offsets fit 32 bits
     uint64_t *residue, *ppr;
     uint64_t *wl[2];
     uint64_t wl_cap;
@@ -151,16 +152,29 @@ __device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg,
     if (deg == DEG_SAT) deg = (uint64_t)(d.row_ptr[v + 1] - beg);
 }
 
+struct __attribute__((packed, aligned(4))) U32Pair { uint32_t a, b; }; // dword-aligned pair: one dwordx2 load
+// column id of edge e from the bit-packed copy
+__device__ __forceinline__ uint32_t colp_at(const Dev &d, uint64_t e) {
+    uint32_t word, sh;
+    if (d.colp32) { // nnz * colbits < 2^32: one 32-bit multiply instead of a 64-bit one (quarter-rate on the VALU)
+        const uint32_t at = d.colbits * (uint32_t)e;
+        word = at >> 5; sh = at & 31;
+    } else {
+        const uint64_t at = (uint64_t)d.colbits * e;
+        word = (uint32_t)(at >> 5); sh = (uint32_t)at & 31;
+    }
+    const U32Pair cw = *(const U32Pair *)(d.colp + word);
+    const uint64_t both = ((uint64_t)cw.b << 32) | cw.a;
+    return (uint32_t)(both >> sh) & ((1u << d.colbits) - 1u);
+}
 // one walk move from `cur` with random word wm: returns the chosen out-neighbour, or `start` when
 // cur is dangling (algo.h:134-140)
 __device__ __forceinline__ uint32_t walk_move(const Dev &d, uint32_t cur, uint32_t start, uint32_t wm) {
     if (d.rp32) {
-        const uint32_t b = d.rp32[cur], dg = d.rp32[cur + 1] - b;
+        const U32Pair rp = *(const U32Pair *)(d.rp32 + cur);
+        const uint32_t dg = rp.b - rp.a;
         if (!dg) return start;
-        const uint64_t at = (uint64_t)d.colbits * (b + __umulhi(wm, dg)); // bit offset of the entry
-        const uint32_t wlo = d.colp[at >> 5], whi = d.colp[(at >> 5) + 1];
-        const uint64_t both = ((uint64_t)whi << 32) | wlo;
-        return (uint32_t)(both >> (at & 31)) & ((1u << d.colbits) - 1u);
+        return colp_at(d, (uint64_t)rp.a + __umulhi(wm, dg));
     }
     int64_t beg; uint64_t deg;
     node_row(d, cur, beg, deg);
@@ -1359,7 +1373,11 @@ __global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, in
                         start = s_v[item];
                         if (MODE == WALK_TO_INDEX) opos = s_pos[item] + jj;
                         else wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0);
-                        node_row(d, start, beg0, deg0);
+                        if (d.rp32) { // keep the whole walk inside the compact copy's working set
+                            const U32Pair rp = *(const U32Pair *)(d.rp32 + start);
+                            beg0 = rp.a;
+                            deg0 = rp.b - rp.a;
+                        } else node_row(d, start, beg0, deg0);
                         cur = start;
                         t = 0;
                         if (deg0 == 0) done = (int32_t)start; // algo.h:127-129
@@ -1381,7 +1399,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, in
                     active = false;
                 } else {
                     if (t) cur = walk_move(d, cur, start, wm);                                             // algo.h:134-140
-                    else cur = (uint32_t)d.col[beg0 + (int64_t)(((uint64_t)wm * deg0) >> 32)];            // deg0 > 0 here
+                    else if (d.rp32) cur = colp_at(d, (uint64_t)beg0 + (((uint64_t)wm * deg0) >> 32));    // deg0 > 0 here
+                    else cur = (uint32_t)d.col[beg0 + (int64_t)(((uint64_t)wm * deg0) >> 32)];
                     t++;
                     steps++;
                 }
