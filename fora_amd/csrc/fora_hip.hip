@@ -482,6 +482,7 @@ int batch_finish(fora_ctx *c) {
         c->timing.pops += c->h_qs[i].pops;
         c->timing.relax += c->h_qs[i].relax;
         c->timing.walks += c->h_qs[i].n_walks;
+        c->timing.idx_hits += c->h_qs[i].n_hit;
     }
     return FORA_OK;
 }
@@ -1040,6 +1041,13 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("topk: ") + hipGetErrorString(e));
         ev_collect(c);
+        HIPCHK(c, hipMemcpy(c->h_qs.data(), c->d_qs, (size_t)nb * sizeof(QState), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nb; i++) { // counters accumulated over all rounds of the slot
+            c->timing.pops += c->h_qs[i].pops;
+            c->timing.relax += c->h_qs[i].relax;
+            c->timing.walks += c->h_qs[i].n_walks;
+            c->timing.idx_hits += c->h_qs[i].n_hit;
+        }
         if (rounds) for (int i = 0; i < nb; i++) rounds[b0 + i] = nround[i];
     }
     return FORA_OK;
@@ -1062,6 +1070,7 @@ int fora_hip_get_timing(fora_ctx *c, fora_timing *out) {
         out->push_pop_launches += w.push_pop_launches; out->push_expand_launches += w.push_expand_launches;
         out->push_accum_launches += w.push_accum_launches; out->walk_launches += w.walk_launches; out->batches += w.batches;
         out->pops += w.pops; out->relax += w.relax; out->walks += w.walks; out->walk_steps += w.walk_steps; out->levels += w.levels;
+        out->idx_hits += w.idx_hits;
     }
     return FORA_OK;
 }

@@ -190,7 +190,7 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     timers.add(RONDOM_WALK, (tm.walk_alloc_ms + tm.walk_ms) * 1e-3);
     timers.add(SORT_MAP, tm.other_ms * 1e-3);
     timers.add(FORA_QUERY, dt);
-    finish(graph, FORA_QUERY, query_size, (double)tm.walks, 0);
+    finish(graph, FORA_QUERY, query_size, (double)tm.walks, (double)tm.idx_hits);
     cout << "top-k lists written to " << out << endl;
     fora_hip_destroy(ctx);
     return 0;

@@ -70,6 +70,7 @@ typedef struct {
     uint64_t walks;
     uint64_t walk_steps;
     uint64_t levels;        /* levels launched (including speculative empty ones) */
+    uint64_t idx_hits;      /* walks served from the index (num_hit_idx, algo.h:39) */
 } fora_timing;
 
 /* ---- lifecycle ---------------------------------------------------------- */
