@@ -682,32 +682,31 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     }
     for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
     __syncthreads();
-    // messages: issue ACC_UNROLL independent loads per lane before the LDS adds that consume them
+    // messages: ACC_UNROLL per lane and iteration, all loads BRANCH-FREE (clamped index, masked afterwards).
+    // With an `if (i < cnt)` around each load hipcc puts every dependent increment gather behind its own
+    // s_waitcnt vmcnt(0): eight serialized round trips per iteration instead of two.
     constexpr int ACC_UNROLL = 8;
+    const bool gather = !TO_PPR && !d.wide;
+    const uint64_t *itab = d.inc_tab + (uint64_t)q * d.segq_cap;
     for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
         uint32_t mw[ACC_UNROLL];
         uint64_t mi[ACC_UNROLL];
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mi[k] = 0;
-            mw[k] = 0;
-            if (i < cnt) {
-                mw[k] = d.bk_w[bk0 + i];
-                if (TO_PPR || d.wide) mi[k] = d.bk_inc[bk0 + i];
-            }
-        }
-        if (!TO_PPR && !d.wide) { // push message: target (BIN_SHIFT bits) | slice index (SEG_BITS bits)
-#pragma unroll
-            for (int k = 0; k < ACC_UNROLL; k++) {
-                const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-                if (i < cnt) mi[k] = d.inc_tab[(uint64_t)q * d.segq_cap + (mw[k] & ((1u << SEG_BITS) - 1))];
-                mw[k] >>= SEG_BITS;
-            }
+            mw[k] = d.bk_w[bk0 + (i < cnt ? i : 0)];
         }
 #pragma unroll
-        for (int k = 0; k < ACC_UNROLL; k++)
-            if (mi[k]) atomicAdd((unsigned long long *)&acc[mw[k] & (BIN_SIZE - 1)], (unsigned long long)mi[k]);
+        for (int k = 0; k < ACC_UNROLL; k++) {
+            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
+            mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : d.bk_inc[bk0 + (i < cnt ? i : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < ACC_UNROLL; k++) {
+            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
+            const uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
+            if (i < cnt && mi[k]) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)mi[k]);
+        }
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
     for (uint32_t i = threadIdx.x; i < ovn; i += ACC_THREADS) { // increments whose bucket was full
