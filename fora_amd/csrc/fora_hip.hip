@@ -65,7 +65,7 @@ struct fora_ctx {
     uint32_t *d_err = nullptr;
     // bucketed push (n <= MAX_BINS * BIN_SIZE)
     bool binned = false;
-    int nbins = 0;
+    int nbins = 0, pbins = 0; // bins of the graph; bins per pass (bucket-array stride)
     uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
     uint64_t *d_inc_tab = nullptr;
     uint32_t *d_ov_w = nullptr, *d_ov_count = nullptr; // bucket overflow list
@@ -154,9 +154,15 @@ constexpr int SPEC = 3;          // levels launched ahead of the frontier-size r
 constexpr int FLC_RING = SPEC + 2;
 
 static bool want_binned(const fora_ctx *c) {
-    const char *e = getenv("FORA_HIP_DIRECT");
-    if (e && e[0] == '1') return false;
-    return (uint64_t)c->n <= (uint64_t)MAX_BINS_WIDE * BIN_SIZE;
+    const char *e = getenv("FORA_HIP_DIRECT"); // tests: the one-atomic-per-edge path
+    (void)c;
+    return !(e && e[0] == '1');
+}
+// bins handled per pass in the wide layout (graphs with more bins run several bin/accum passes per level)
+static int want_pass_bins() {
+    const char *e = getenv("FORA_HIP_PASS_BINS");
+    if (e && atoi(e) > 0) return std::min(atoi(e), (int)MAX_BINS_WIDE);
+    return MAX_BINS_WIDE;
 }
 // narrow layout: <= MAX_BINS bins and the slice index fits the 4-byte push message
 static bool want_wide(const fora_ctx *c) {
@@ -175,7 +181,7 @@ static uint32_t want_bk_cap_wide() { // push messages only (walk results go by d
     return 196608; // also holds the indexed walk results (~omega*rsum/nbins per bucket)
 }
 
-struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
+struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
 // (the wide / narrow choice changes bk_cap, which forces a re-plan of the workspace)
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     WsPlan p{};
@@ -187,10 +193,11 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
+        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins()) : p.nbins;
         p.bk_cap = want_wide(c) ? want_bk_cap_wide() : want_bk_cap();
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + 262144ull * 12 + (uint64_t)p.nbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + 262144ull * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -212,7 +219,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
     const uint64_t n = (uint64_t)c->n;
     const uint64_t scratch = (uint64_t)B * p.scratch;
-    if (c->B >= B && c->binned == p.binned && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return FORA_OK;
+    if (c->B >= B && c->binned == p.binned && c->pbins == p.pbins && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return FORA_OK;
     free_workspace(c);
     const uint64_t slab = (uint64_t)B * n;
     HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
@@ -226,9 +233,9 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
-        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.nbins * p.bk_cap * 4));
-        HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.nbins * p.bk_cap * 8));
-        HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.nbins * 4 * CSTRIDE));
+        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.bk_cap * 4));
+        HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.bk_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * 4 * CSTRIDE));
         HIPCHK(c, hipHostMalloc(&c->h_flc, (size_t)FLC_RING * B * 4 * CSTRIDE));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
@@ -244,7 +251,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipHostMalloc(&c->h_qs_pin, (size_t)B * sizeof(QState)));
     HIPCHK(c, hipHostMalloc(&c->h_steps_pin, sizeof(unsigned long long)));
     c->B = B;
-    c->binned = p.binned; c->nbins = p.nbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
+    c->binned = p.binned; c->nbins = p.nbins; c->pbins = p.pbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
     c->wl_cap = slab;
     c->seg_cap = scratch / sizeof(PushSeg);
     c->wit_cap = p.wits; // per slot
@@ -276,6 +283,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.seed_lo = (uint32_t)c->seed; d.seed_hi = (uint32_t)(c->seed >> 32);
     d.alpha = c->alpha; d.omega = omega; d.opt = c->opt;
     d.binned = c->binned ? 1 : 0; d.nbins = c->nbins; d.wide = c->binned && want_wide(c) ? 1 : 0;
+    d.pbins = c->pbins; d.bin_lo = 0; d.bin_cnt = std::min(c->pbins, c->nbins);
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
     d.inc_tab = c->d_inc_tab; d.segq_cap = c->segq_cap;
@@ -347,13 +355,18 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     for (;; L++) {
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
         if (c->binned) {
-            int h = ev_begin(c, 1);
-            if (d.wide) hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
-            else hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, d, L);
-            ev_end(c, h);
-            h = ev_begin(c, 6);
-            hipLaunchKernelGGL(k_accum<false>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, L);
-            ev_end(c, h);
+            for (int lo = 0; lo < c->nbins; lo += c->pbins) { // one pass per group of pbins bins (usually one)
+                Dev dp = d;
+                dp.bin_lo = lo;
+                dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
+                int h = ev_begin(c, 1);
+                if (d.wide) hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                else hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                ev_end(c, h);
+                h = ev_begin(c, 6);
+                hipLaunchKernelGGL(k_accum<false>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
+                ev_end(c, h);
+            }
             (void)hipMemcpyAsync(c->h_flc + (size_t)((L + 1) % FLC_RING) * c->B * CSTRIDE, d.fl_count[(L + 1) & 1],
                                  (size_t)nq * 4 * CSTRIDE, hipMemcpyDeviceToHost, c->stream);
         } else {
@@ -397,7 +410,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
 int reset_binned_counters(fora_ctx *c) {
     if (!c->binned) return FORA_OK;
     HIPCHK(c, hipMemsetAsync(c->d_fl_count, 0, (size_t)c->B * 2 * 4 * CSTRIDE, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->nbins * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
     return FORA_OK;
 }
@@ -417,6 +430,31 @@ int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
 }
 
 enum { RUN_PUSH_ONLY = 1 };
+
+// refinement launches after k_walk_alloc: indexed walks, online walks, and the accumulate of their results
+void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t round, int nzh) {
+    const dim3 wg(walk_grid_x(nq), nq);
+    int h = ev_begin(c, 3);
+    if (with_idx) {
+        if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, wg, dim3(BLOCK), 0, c->stream, d);
+        else if (!d.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, wg, dim3(BLOCK), 0, c->stream, d);
+        else
+            for (int lo = 0; lo < c->nbins; lo += c->pbins) { // buckets are reused pass by pass
+                Dev dp = d;
+                dp.bin_lo = lo;
+                dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
+                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wg, dim3(BLOCK), 0, c->stream, dp);
+                hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
+            }
+    }
+    hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
+    ev_end(c, h);
+    if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets
+        h = ev_begin(c, 7);
+        hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
+        ev_end(c, h);
+    }
+}
 
 // one batch of <= B sources: push (+ refinement).  Results stay in the slabs.
 // one batch of <= B sources, part 1: push (host-driven level loop, returns when the push is done)
@@ -439,20 +477,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
         hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
                            (const uint8_t *)nullptr, (uint64_t *)nullptr);
         ev_end(c, h);
-        h = ev_begin(c, 3);
-        if (with_idx) {
-            if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
-            else if (d.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
-            else hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d);
-        }
-        hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nq), nq), dim3(BLOCK), 0, c->stream, d, 0u,
-                           c->opt ? 1 : 0, (int32_t *)nullptr);
-        ev_end(c, h);
-        if (c->binned && (!d.wide || with_idx)) {
-            h = ev_begin(c, 7);
-            hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
-            ev_end(c, h);
-        }
+        launch_walks(c, d, nq, with_idx, 0u, c->opt ? 1 : 0);
     }
     {
         const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 64);
@@ -1000,20 +1025,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
                                (const uint8_t *)c->d_active, c->d_cursor);
             ev_end(c, h);
-            h = ev_begin(c, 3);
-            if (with_idx) {
-                if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
-                else if (dw.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
-                else hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw);
-            }
-            hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, dim3(walk_grid_x(nb), nb), dim3(BLOCK), 0, c->stream, dw,
-                               (uint32_t)round, with_idx ? 1 : 0, (int32_t *)nullptr);
-            ev_end(c, h);
-            if (c->binned && (!dw.wide || with_idx)) {
-                h = ev_begin(c, 7);
-                hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nb), dim3(ACC_THREADS), 0, c->stream, dw, 0);
-                ev_end(c, h);
-            }
+            launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, with_idx ? 1 : 0);
             const double T = (1 + epsilon) * delta; // query.h:1030
             h = ev_begin(c, 4);
             hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,

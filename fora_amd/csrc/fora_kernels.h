@@ -101,7 +101,9 @@ struct Dev {
     const int32_t *rw_idx;
     const uint64_t *idx_off, *idx_cnt;
     // ---- bucketed push state (binned != 0)
-    int32_t binned, nbins;
+    int32_t binned, nbins;  // nbins: bins of the whole graph
+    int32_t pbins;          // bins per pass = stride of the bucket arrays (<= MAX_BINS_WIDE)
+    int32_t bin_lo, bin_cnt; // bins [bin_lo, bin_lo + bin_cnt) are handled by the current pass
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
     uint64_t *inc_tab;      // [slot][segq_cap] increment of the node at frontier position i (gathered by k_accum)
@@ -476,7 +478,8 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     const int q = blockIdx.y;
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool first_pass = d.bin_lo == 0; // graphs with more than pbins bins run several bin/accum passes per level
+    if (first_pass && blockIdx.x == 0 && threadIdx.x == 0) {
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
     }
@@ -493,15 +496,23 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t *in = d.fl[par] + slab;
     uint64_t *incs = d.inc_tab + (uint64_t)q * d.segq_cap;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
+    const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
     for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < count; tbase += gridDim.x * BLOCK) {
         // ---- pop: one frontier node per lane
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
-        if (i < count) {
+        if (i < count && !first_pass) { // later pass of this level: the node was popped in pass 0
+            const uint32_t v = in[i];
+            int64_t beg; uint64_t deg;
+            node_row(d, v, beg, deg);
+            s_ebeg[threadIdx.x] = beg;
+            s_inc[threadIdx.x] = incs[i];
+            cnt = (uint32_t)deg;
+        } else if (i < count) {
             const uint32_t v = in[i];
             const uint64_t a = slab + v;
             const uint64_t r = d.residue[a];
@@ -525,7 +536,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
             acc_relax += deg;
             s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = inc;
-            if (!WIDE) incs[i] = inc;
+            incs[i] = inc;
             cnt = (uint32_t)deg;
         }
         uint32_t total;
@@ -559,9 +570,12 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 if (e < total) w[k] = (uint32_t)d.col[s_ebeg[si[k]] + (e - s_pref[si[k]])];
             }
 #pragma unroll
-            for (int k = 0; k < BIN_EPT; k++)
-                if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[w[k] >> BIN_SHIFT], 1u); // rank inside (chunk, bin)
+            for (int k = 0; k < BIN_EPT; k++) {
+                if (w[k] != 0xFFFFFFFFu && (w[k] >> BIN_SHIFT) - bin_lo >= bin_cnt) w[k] = 0xFFFFFFFFu; // another pass's bins
+                if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(w[k] >> BIN_SHIFT) - bin_lo], 1u); // rank inside (chunk, bin)
+            }
             __syncthreads();
+            uint32_t staged; // messages of this chunk that belong to the pass's bins
             { // reserve bucket space (ONE global atomic per (chunk, bin)) and lay the bins out in the LDS stage:
               // lane t owns bins t*PER .. t*PER+PER-1
                 constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
@@ -569,11 +583,12 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
-                    c[j] = b < (uint32_t)d.nbins && b < (uint32_t)NB ? s_cnt[b] : 0;
+                    c[j] = b < (uint32_t)d.bin_cnt && b < (uint32_t)NB ? s_cnt[b] : 0;
                     mine += c[j];
                 }
                 uint32_t ctot;
                 uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
+                staged = ctot;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
@@ -588,11 +603,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 }
             }
             __syncthreads();
-            const uint32_t ctotal = total - cb < BLOCK * BIN_EPT ? total - cb : BLOCK * BIN_EPT;
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
                 if (w[k] != 0xFFFFFFFFu) {
-                    const uint32_t b = w[k] >> BIN_SHIFT;
+                    const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
                     if (WIDE) { s_msg[sp] = w[k] & (BIN_SIZE - 1); s_sidx[sp] = si[k]; }
@@ -608,7 +622,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 }
             }
             __syncthreads();
-            for (uint32_t m = threadIdx.x; m < ctotal; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
+            for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t dst = s_dst[m];
                 if (dst != 0xFFFFFFFFu) {
                     d.bk_w[bk0 + dst] = s_msg[m];
@@ -620,7 +634,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     }
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
-    if (lane == 0 && acc_pops) {
+    if (lane == 0 && acc_pops) { // (only the first pass pops)
         QState *s = &d.qs[q];
         atomicAdd(&s->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
         if (acc_dang) atomicAdd(&s->dang, (unsigned long long)acc_dang);
@@ -630,14 +644,15 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     }
 }
 
-// grid = (nbins, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
+// grid = (bins of the pass, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
 // to the ppr slab and there is no threshold / frontier.
 template <bool TO_PPR>
 __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint64_t acc[BIN_SIZE];
-    const int b = blockIdx.x, q = blockIdx.y;
+    const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
+    const int b = d.bin_lo + lb;
     const uint64_t slab = (uint64_t)q * d.n;
-    const uint32_t bi = (uint32_t)q * d.nbins + b;
+    const uint32_t bi = (uint32_t)q * d.pbins + lb;
     uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
     if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess is in the overflow list (push) / went by direct atomics (walks)
     const uint32_t s = (uint32_t)d.src[q];
@@ -1112,8 +1127,8 @@ struct WaveStage {
 __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) {
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
     st.bcnt[lane] = 0;
     st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -1190,8 +1205,9 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     if (!nitems) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.nbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.nbins * d.bk_cap;
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
+    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
+    const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
     if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
         const uint32_t i = tbase + threadIdx.x;
@@ -1247,20 +1263,24 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                 continue;
             }
 #pragma unroll
-            for (int k = 0; k < EPT; k++)
-                if (dest[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[dest[k] >> BIN_SHIFT], 1u);
+            for (int k = 0; k < EPT; k++) {
+                if (dest[k] != 0xFFFFFFFFu && (dest[k] >> BIN_SHIFT) - bin_lo >= bin_cnt) dest[k] = 0xFFFFFFFFu; // another pass
+                if (dest[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(dest[k] >> BIN_SHIFT) - bin_lo], 1u);
+            }
             __syncthreads();
+            uint32_t staged; // results of this chunk that belong to the pass's bins
             {
                 constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
                 uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
-                    c[j] = b < (uint32_t)d.nbins && b < (uint32_t)NB ? s_cnt[b] : 0;
+                    c[j] = b < (uint32_t)d.bin_cnt && b < (uint32_t)NB ? s_cnt[b] : 0;
                     mine += c[j];
                 }
                 uint32_t ctot;
                 uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
+                staged = ctot;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
@@ -1275,11 +1295,10 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                 }
             }
             __syncthreads();
-            const uint32_t ctotal = total - cb < BLOCK * EPT ? total - cb : BLOCK * EPT;
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 if (dest[k] != 0xFFFFFFFFu) {
-                    const uint32_t b = dest[k] >> BIN_SHIFT;
+                    const uint32_t b = (dest[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
                     s_msg[sp] = dest[k];
@@ -1290,7 +1309,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                 }
             }
             __syncthreads();
-            for (uint32_t m = threadIdx.x; m < ctotal; m += BLOCK) {
+            for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) {
                 const uint32_t dst = s_dst[m];
                 if (dst != 0xFFFFFFFFu) {
                     d.bk_w[bk0 + dst] = s_msg[m];

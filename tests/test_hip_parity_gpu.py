@@ -243,7 +243,8 @@ def test_topk_argument_checks(engine, oracle, tiny):
         engine.topk(np.array([1], dtype=np.int32), 10, epsilon=0.5, with_idx=True)
 
 
-@pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow"])
+@pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow",
+                                  "bucketed_wide_multipass"])
 def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
     """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
     overflow fallback all give the twin's bits (integer adds commute)."""
@@ -257,6 +258,9 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     elif mode == "bucketed_wide_overflow":
         monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
         monkeypatch.setenv("FORA_HIP_BKCAP", "200")
+    elif mode == "bucketed_wide_multipass":  # the layout of graphs with more than 1024 bins: several passes per level
+        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
+        monkeypatch.setenv("FORA_HIP_PASS_BINS", "1")
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = np.concatenate([pick_sources(g, 7, 51), pick_sources(g, 1, 52, want_dangling=True)])
     ppr, res, st = engine.query_fix(srcs)
@@ -266,7 +270,16 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["levels"] == wst["levels"]
     monkeypatch.delenv("FORA_HIP_DIRECT", raising=False)
     monkeypatch.delenv("FORA_HIP_BKCAP", raising=False)
+    if mode == "bucketed_wide_multipass":  # indexed walks and top-k take the per-pass route too
+        engine.build_index()
+        idx = engine.get_index()
+        pi, _, _ = engine.query_fix(srcs[:3], with_idx=True, want_residue=False)
+        for i, s in enumerate(srcs[:3]):
+            want, _, _ = oracle.twin_query(g, int(s), rmax, omega, seed=SEED, index=idx)
+            assert (pi[i] == want).all()
+        engine.clear_index()
     monkeypatch.delenv("FORA_HIP_FORCE_WIDE", raising=False)
+    monkeypatch.delenv("FORA_HIP_PASS_BINS", raising=False)
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
