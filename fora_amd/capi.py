@@ -11,7 +11,7 @@ FIX_ONE = 1 << 62
 STREAM_INDEX = 0xFFFFFFFF
 
 SYMBOLS = [
-    "fora_hip_create", "fora_hip_destroy", "fora_hip_last_error", "fora_hip_device_info",
+    "fora_hip_create", "fora_hip_destroy", "fora_hip_device_count", "fora_hip_last_error", "fora_hip_device_info",
     "fora_hip_set_graph", "fora_hip_set_params", "fora_hip_set_params_raw", "fora_hip_get_params",
     "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",

@@ -620,6 +620,12 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
 // =============================================================================== C ABI
 extern "C" {
 
+int fora_hip_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
+}
+
 int fora_hip_create(int device, fora_ctx **out) {
     if (!out) return FORA_E_ARG;
     *out = nullptr;

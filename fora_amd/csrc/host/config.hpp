@@ -49,6 +49,7 @@ struct Config { // config.h:86-160
     uint64_t seed = 0x464F5241ull;
     int device = 0;
     int batch = 0;
+    int gpus = 1;   // --gpus N: sources i mod N on GPU (device + i mod N), one host thread per GPU
     std::string get_graph_folder() const { return prefix + graph_alias + "/"; } // config.h:99-101
 };
 

@@ -38,29 +38,44 @@ struct Graph {
     bool init_graph() { // graph.h:89-163, plain branch :151-161
         if (!init_nm()) return false;
         const std::string f = data_folder + "graph.txt";
-        FILE *fp = fopen(f.c_str(), "r");
+        FILE *fp = fopen(f.c_str(), "rb");
         if (!fp) { error = "graph file " + f + " not find"; return false; }
         std::vector<int32_t> src, dst;
         src.reserve((size_t)(m > 0 ? m : 0));
         dst.reserve((size_t)(m > 0 ? m : 0));
-        int t1, t2;
-        while (fscanf(fp, "%d%d", &t1, &t2) == 2) {
-            if (t1 >= n || t2 >= n || t1 < 0 || t2 < 0) { // assert(t1 < n); assert(t2 < n);
-                fclose(fp);
-                error = "node id out of range in graph.txt";
-                return false;
+        // same token stream as `fscanf("%d%d")` (graph.h:152-154) -- whitespace-separated decimal integers, stop
+        // at the first thing that is not one -- read in 16 MiB blocks instead of one libc call per number
+        std::vector<char> buf(16u << 20);
+        long long cur = 0, first = 0;
+        bool in_num = false, neg = false, have_first = false, bad = false, stop = false;
+        auto flush_num = [&]() {
+            const long long v = neg ? -cur : cur;
+            if (!have_first) { first = v; have_first = true; return; }
+            have_first = false;
+            if (first >= n || v >= n || first < 0 || v < 0) { bad = true; return; } // assert(t1 < n); assert(t2 < n);
+            if (first == v) return;                                                 // graph.h:157
+            src.push_back((int32_t)first);
+            dst.push_back((int32_t)v);
+        };
+        size_t got;
+        while (!stop && !bad && (got = fread(buf.data(), 1, buf.size(), fp)) > 0) {
+            for (size_t i = 0; i < got && !bad; i++) {
+                const char ch = buf[i];
+                if (ch >= '0' && ch <= '9') { cur = in_num ? cur * 10 + (ch - '0') : (ch - '0'); in_num = true; }
+                else if (ch == '-' && !in_num) { neg = true; in_num = true; cur = 0; }
+                else if (ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r') { if (in_num) { flush_num(); in_num = false; neg = false; } }
+                else { stop = true; break; } // fscanf would fail to match here
             }
-            if (t1 == t2) continue; // graph.h:157
-            src.push_back(t1);
-            dst.push_back(t2);
         }
+        if (in_num && !bad) flush_num();
         fclose(fp);
+        if (bad) { error = "node id out of range in graph.txt"; return false; }
         row_ptr.assign((size_t)n + 1, 0);
         for (int32_t s : src) row_ptr[(size_t)s + 1]++;
         for (int32_t v = 0; v < n; v++) row_ptr[(size_t)v + 1] += row_ptr[v];
         col.resize(src.size());
-        std::vector<int64_t> cur(row_ptr.begin(), row_ptr.end() - 1);
-        for (size_t e = 0; e < src.size(); e++) col[(size_t)cur[src[e]]++] = dst[e];
+        std::vector<int64_t> fill(row_ptr.begin(), row_ptr.end() - 1);
+        for (size_t e = 0; e < src.size(); e++) col[(size_t)fill[src[e]]++] = dst[e];
         return true;
     }
 

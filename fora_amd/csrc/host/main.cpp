@@ -12,6 +12,7 @@
 #include <cstring>
 #include <iostream>
 #include <sys/resource.h>
+#include <thread>
 
 using namespace forahost;
 using std::cerr;
@@ -53,7 +54,8 @@ static const char *HELP =
     "  --result_dir <directory to place results>\n"
     "  --rmax_scale <scale of rmax>\n"
     "  --seed <walk RNG seed>   (MI355X build: Philox, reproducible)\n"
-    "  --device <gpu ordinal>   --batch <queries in flight>\n";
+    "  --device <gpu ordinal>   --batch <queries in flight>\n"
+    "  --gpus <N>               (sources i mod N on N GPUs of this node, one host thread per GPU)\n";
 
 #define FAIL(ctx, what)                                                                        \
     do {                                                                                       \
@@ -85,8 +87,8 @@ static void finish(const Graph &graph, int used_counter, unsigned query_size, do
     if (config.action == TOPK) result.topk_sort_time = timers.get(SORT_MAP);
 }
 
-static int open_engine(const Graph &graph, fora_ctx **ctx) {
-    int rc = fora_hip_create(config.device, ctx);
+static int open_engine(const Graph &graph, fora_ctx **ctx, int device = -1) {
+    int rc = fora_hip_create(device < 0 ? config.device : device, ctx);
     if (rc) { cerr << "no usable MI355X (gfx950) device: fora_hip_create rc=" << rc << endl; return 1; }
     if (fora_hip_set_graph(*ctx, graph.n, graph.m, graph.row_ptr.data(), graph.col.data())) FAIL(*ctx, "set_graph");
     if (fora_hip_set_params(*ctx, config.alpha, config.epsilon, config.rmax_scale, config.opt, config.seed)) FAIL(*ctx, "set_params");
@@ -95,16 +97,66 @@ static int open_engine(const Graph &graph, fora_ctx **ctx) {
     return 0;
 }
 
-static int load_index(fora_ctx *ctx, const Graph &graph) { // deserialize_idx, build.h:194-207
-    std::vector<int32_t> rw;
-    std::vector<uint64_t> off, cnt;
+// ---- multi-GPU: one host thread and one context per GPU, source i of the query list on shard i mod G
+// (the per-source loops of query.h:1471-1476 / 1397-1401 carry no state from one source to the next)
+struct IndexData { std::vector<int32_t> rw; std::vector<uint64_t> off, cnt; };
+struct Shard {
+    std::vector<int32_t> sources;
+    std::vector<unsigned> pos; // position of each source in the query list
+    fora_timing tm{};
+    double seconds = 0;
+    int rc = 0;
     string err;
-    if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)) {
-        cerr << err << endl;
-        return 1;
+};
+
+template <class Work> // Work(ctx, shard) -> rc, runs the shard's batch call and scatters its outputs
+static int run_sharded(const Graph &graph, const std::vector<int32_t> &queries, unsigned query_size,
+                       const IndexData *index, std::vector<Shard> &shards, Work work) {
+    int ndev = fora_hip_device_count();
+    if (ndev <= 0) { cerr << "no usable MI355X (gfx950) device" << endl; return 1; }
+    const int G = std::max(1, config.gpus);
+    shards.assign((size_t)G, Shard());
+    for (unsigned i = 0; i < query_size; i++) {
+        shards[i % G].sources.push_back(queries[i]);
+        shards[i % G].pos.push_back(i);
     }
-    if (fora_hip_set_index(ctx, rw.data(), rw.size(), off.data(), cnt.data())) FAIL(ctx, "set_index");
+    std::vector<std::thread> threads;
+    for (int g = 0; g < G; g++)
+        threads.emplace_back([&, g]() {
+            Shard &s = shards[(size_t)g];
+            fora_ctx *ctx = nullptr;
+            if (fora_hip_create((config.device + g) % ndev, &ctx)) { s.rc = 1; s.err = "fora_hip_create failed"; return; }
+            auto bail = [&](const char *what) { s.rc = 1; s.err = string(what) + ": " + fora_hip_last_error(ctx); fora_hip_destroy(ctx); };
+            if (fora_hip_set_graph(ctx, graph.n, graph.m, graph.row_ptr.data(), graph.col.data())) return bail("set_graph");
+            if (fora_hip_set_params(ctx, config.alpha, config.epsilon, config.rmax_scale, config.opt, config.seed)) return bail("set_params");
+            if (config.batch) fora_hip_set_batch(ctx, config.batch);
+            if (index && fora_hip_set_index(ctx, index->rw.data(), index->rw.size(), index->off.data(), index->cnt.data()))
+                return bail("set_index");
+            fora_hip_reset_timing(ctx);
+            const double t0 = now_s();
+            if (work(ctx, s)) return bail("run");
+            s.seconds = now_s() - t0;
+            fora_hip_get_timing(ctx, &s.tm);
+            fora_hip_destroy(ctx);
+        });
+    for (auto &t : threads) t.join();
+    for (auto &s : shards)
+        if (s.rc) { cerr << s.err << endl; return 1; }
     return 0;
+}
+
+static void add_shard_timers(const std::vector<Shard> &shards, int total_slot) {
+    double wall = 0, push = 0, walk = 0, other = 0;
+    for (auto &s : shards) { // shards run concurrently: the slowest one is the elapsed time
+        wall = std::max(wall, s.seconds);
+        push = std::max(push, (s.tm.push_pop_ms + s.tm.push_expand_ms + s.tm.push_accum_ms) * 1e-3);
+        walk = std::max(walk, (s.tm.walk_alloc_ms + s.tm.walk_ms + s.tm.walk_accum_ms) * 1e-3);
+        other = std::max(other, s.tm.other_ms * 1e-3);
+    }
+    timers.add(total_slot, wall);
+    timers.add(FWD_LU, push);
+    timers.add(RONDOM_WALK, walk);
+    if (config.action == TOPK) timers.add(SORT_MAP, other);
 }
 
 static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
@@ -114,18 +166,31 @@ static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
     unsigned query_size = std::min<unsigned>((unsigned)queries.size(), config.query_size);
     info("query_size", query_size);
     if (!(config.rmax_scale >= 0)) { cerr << "rmax_scale must be >= 0" << endl; return 1; } // query.h:1424
-    fora_ctx *ctx = nullptr;
-    if (open_engine(graph, &ctx)) return 1;
+    { // fora_setting (algo.h:455-463) for the log lines / result JSON; the engine recomputes the same values
+        const double delta = 1.0 / graph.n, pfail = 1.0 / graph.n;
+        config.rmax = config.epsilon * sqrt(delta / 3 / graph.m / log(2 / pfail));
+        config.rmax *= config.opt ? config.rmax_scale / (1 - config.alpha) : config.rmax_scale;
+        config.omega = (2 + config.epsilon) * log(2 / pfail) / delta / config.epsilon / config.epsilon;
+    }
     info("config.rmax", config.rmax);
     info("config.omega", config.omega);
-    if (config.with_rw_idx && load_index(ctx, graph)) { fora_hip_destroy(ctx); return 1; }
+    IndexData index;
+    if (config.with_rw_idx) { // deserialize_idx, build.h:194-207
+        string err;
+        if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, index.rw, index.off, index.cnt, err)) {
+            cerr << err << endl;
+            return 1;
+        }
+    }
     std::vector<fora_query_stats> st(query_size);
-    fora_hip_reset_timing(ctx);
-    const double t0 = now_s();
-    if (fora_hip_query_batch(ctx, queries.data(), (int)query_size, config.with_rw_idx, nullptr, st.data())) FAIL(ctx, "query");
-    const double dt = now_s() - t0;
-    fora_timing tm;
-    fora_hip_get_timing(ctx, &tm);
+    std::vector<Shard> shards;
+    if (run_sharded(graph, queries, query_size, config.with_rw_idx ? &index : nullptr, shards, [&](fora_ctx *ctx, Shard &s) {
+            std::vector<fora_query_stats> local(s.sources.size());
+            if (fora_hip_query_batch(ctx, s.sources.data(), (int)s.sources.size(), config.with_rw_idx, nullptr, local.data())) return 1;
+            for (size_t i = 0; i < local.size(); i++) st[s.pos[i]] = local[i];
+            return 0;
+        }))
+        return 1;
     double n_walks = 0, n_hit = 0, total_rsum = 0;
     for (unsigned i = 0; i < query_size; i++) {
         cout << i + 1 << ". source node:" << queries[i] << endl; // query.h:1473
@@ -135,11 +200,8 @@ static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
     }
     split_line();
     info("avg_rsum*config.omega", total_rsum / query_size * config.omega);
-    timers.add(FORA_QUERY, dt);
-    timers.add(FWD_LU, (tm.push_pop_ms + tm.push_expand_ms) * 1e-3);
-    timers.add(RONDOM_WALK, (tm.walk_alloc_ms + tm.walk_ms) * 1e-3);
+    add_shard_timers(shards, FORA_QUERY);
     finish(graph, FORA_QUERY, query_size, n_walks, n_hit);
-    fora_hip_destroy(ctx);
     return 0;
 }
 
@@ -155,19 +217,35 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
         cerr << "topk without --opt (bounds variant) is not part of this build; pass --opt" << endl;
         return 1;
     }
-    fora_ctx *ctx = nullptr;
-    if (open_engine(graph, &ctx)) return 1;
-    if (config.with_rw_idx && load_index(ctx, graph)) { fora_hip_destroy(ctx); return 1; }
+    IndexData index;
+    if (config.with_rw_idx) {
+        string err;
+        if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, index.rw, index.off, index.cnt, err)) {
+            cerr << err << endl;
+            return 1;
+        }
+    }
     std::vector<int32_t> ids((size_t)query_size * config.k), rounds(query_size);
     std::vector<double> scores((size_t)query_size * config.k);
-    fora_hip_reset_timing(ctx);
-    const double t0 = now_s();
-    if (fora_hip_topk_batch(ctx, queries.data(), (int)query_size, (int)config.k, config.epsilon, config.rmax_scale,
-                            config.with_rw_idx, ids.data(), scores.data(), rounds.data()))
-        FAIL(ctx, "topk");
-    const double dt = now_s() - t0;
-    fora_timing tm;
-    fora_hip_get_timing(ctx, &tm);
+    std::vector<Shard> shards;
+    const size_t k = config.k;
+    if (run_sharded(graph, queries, query_size, config.with_rw_idx ? &index : nullptr, shards, [&](fora_ctx *ctx, Shard &s) {
+            const size_t nl = s.sources.size();
+            std::vector<int32_t> lid(nl * k), lr(nl);
+            std::vector<double> lsc(nl * k);
+            if (fora_hip_topk_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon, config.rmax_scale, config.with_rw_idx,
+                                    lid.data(), lsc.data(), lr.data()))
+                return 1;
+            for (size_t i = 0; i < nl; i++) { // the "gather": top-k lists back in query order
+                std::copy(lid.begin() + (long)(i * k), lid.begin() + (long)((i + 1) * k), ids.begin() + (long)(s.pos[i] * k));
+                std::copy(lsc.begin() + (long)(i * k), lsc.begin() + (long)((i + 1) * k), scores.begin() + (long)(s.pos[i] * k));
+                rounds[s.pos[i]] = lr[i];
+            }
+            return 0;
+        }))
+        return 1;
+    double tot_walks = 0, tot_hits = 0;
+    for (auto &s : shards) { tot_walks += (double)s.tm.walks; tot_hits += (double)s.tm.idx_hits; }
     long num_iter_topk = 0;
     if (config.exe_result_dir.empty() || config.exe_result_dir.back() != '/') config.exe_result_dir += "/";
     make_dirs(config.exe_result_dir);
@@ -185,14 +263,10 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     if (fo) fclose(fo);
     split_line();
     cout << "average iter times:" << num_iter_topk / query_size << endl; // query.h:1403
-    timers.add(0, dt);
-    timers.add(FWD_LU, (tm.push_pop_ms + tm.push_expand_ms) * 1e-3);
-    timers.add(RONDOM_WALK, (tm.walk_alloc_ms + tm.walk_ms) * 1e-3);
-    timers.add(SORT_MAP, tm.other_ms * 1e-3);
-    timers.add(FORA_QUERY, dt);
-    finish(graph, FORA_QUERY, query_size, (double)tm.walks, (double)tm.idx_hits);
+    add_shard_timers(shards, FORA_QUERY);
+    timers.add(0, timers.get(FORA_QUERY));
+    finish(graph, FORA_QUERY, query_size, tot_walks, tot_hits);
     cout << "top-k lists written to " << out << endl;
-    fora_hip_destroy(ctx);
     return 0;
 }
 
@@ -261,6 +335,7 @@ int main(int argc, char *argv[]) {
         else if (arg == "--seed") config.seed = strtoull(next("--seed"), nullptr, 0);
         else if (arg == "--device") config.device = atoi(next("--device"));
         else if (arg == "--batch") config.batch = atoi(next("--batch"));
+        else if (arg == "--gpus") config.gpus = std::max(1, atoi(next("--gpus")));
         else if (arg.substr(0, 2) == "--") { cerr << "command not recognize " << arg << endl; return 1; } // fora.cpp:156-159
     }
     info("config.version", config.version);

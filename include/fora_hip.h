@@ -74,6 +74,7 @@ typedef struct {
 } fora_timing;
 
 /* ---- lifecycle ---------------------------------------------------------- */
+int fora_hip_device_count(void); /* usable HIP devices (0 when there is none) */
 int fora_hip_create(int device, fora_ctx **out);
 void fora_hip_destroy(fora_ctx *ctx);
 const char *fora_hip_last_error(fora_ctx *ctx);
