@@ -1,14 +1,18 @@
-// fora_kernels.h -- device-side data layout and kernels of the FORA SSPPR engine (gfx950).
+// fora_kernels.h -- device-side data layout and kernels of the FORA SSPPR engine (gfx950, wave64).
 //
-// Hot path of wangsibovictor/fora re-designed for MI355X:
-//   forward push   algo.h:954-1018  -> k_push_pop + k_push_expand, one pair per level
-//   walk allocation query.h:270-287 -> k_walk_alloc
-//   random walks   algo.h:124-166, query.h:288-323 -> k_walk<MODE>
-//   index build    build.h:325-354  -> k_index_alloc + k_walk<WALK_TO_INDEX>
-// Many source queries ("slots") run concurrently; slot q owns dense slabs
-// residue[q*n .. (q+1)*n) and ppr[q*n ..) of 2^-62 fixed-point u64 in HBM.
-// All cross-thread accumulation is integer atomics, so results do not depend on
-// the order atomics land in: the whole path is bit-reproducible.
+// Hot path of wangsibovictor/fora re-designed for MI355X (citations into the reference):
+//   forward push    algo.h:954-1018   -> k_pushq_popbin<NB> + k_accum<false>, one pair per level and bin pass
+//                                        (k_push_pop + k_push_expand: the one-atomic-per-edge form, test reference)
+//   walk allocation query.h:270-287   -> k_walk_alloc<MODE>
+//   random walks    algo.h:124-166, query.h:288-323 -> k_walk_idx<NB>, k_walk_online<MODE>, k_accum<true>
+//   index build     build.h:325-354   -> k_index_alloc + k_walk_online<WALK_TO_INDEX>
+//   top-k           query.h:972-1045, algo.h:578-610 -> k_topk_frontier, k_count_above, k_topk_select
+// Many source queries ("slots") run concurrently; slot q owns dense slabs residue[q*n .. (q+1)*n) and
+// ppr[q*n ..) of 2^-62 fixed-point u64 in HBM.  Every cross-thread accumulation is an integer add (LDS
+// ds_add_u64 inside a workgroup that owns the target range, integer atomics otherwise), so results do not
+// depend on the order adds land in: the whole path is bit-reproducible and checked bit for bit against
+// oracle/fora_twin.c.  Global atomics run at ~23 G/s chip-wide on MI355X whatever their type or scope
+// (profiles/r01_atomics_microbench.txt), hence the LDS-bucketed organisation.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1086,9 +1090,6 @@ enum { WALK_TO_PPR = 0, WALK_TO_INDEX = 1 };
 
 // One alpha-terminated walk under the Philox contract (see oracle/fora_oracle.c orc_walk;
 // semantics algo.h:124-142 and, with nzh, algo.h:144-166).
-struct WalkRng {
-    uint32_t w[4];
-};
 __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64_t j, uint32_t stream,
                                             uint32_t round, int nzh, uint32_t &steps) {
     int64_t beg; uint64_t deg;
