@@ -197,7 +197,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
         p.bk_cap = want_wide(c) ? want_bk_cap_wide() : want_bk_cap();
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + 262144ull * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -229,7 +229,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_fl[1], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
         HIPCHK(c, hipMalloc(&c->d_inc_tab, (uint64_t)B * p.segq_cap * 8));
-        c->ov_cap = 262144;
+        c->ov_cap = (uint32_t)std::max<uint64_t>(262144, n / 8); // bucket-overflow list, scales with the graph
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));

@@ -29,13 +29,16 @@ def _rmat_pairs(rng, scale, count, a=0.57, b=0.19, c=0.19):
     return src, dst
 
 
-def rmat_graph(n, m, seed, dangling="none"):
+def rmat_graph(n, m, seed, dangling="none", fold=False):
     """Directed R-MAT (0.57, 0.19, 0.19, 0.05) edge list with exactly m distinct
     non-loop edges over n nodes, node ids randomly permuted.
 
     dangling="none": every node first gets one uniform random out-edge (real
       web-Stanford has almost no zero-out-degree nodes), the rest is R-MAT.
     dangling="rmat": plain R-MAT (about 43 % zero-out-degree nodes at ws size).
+    fold=True maps R-MAT ids >= n back with `% n` instead of rejecting the pair (3-4x fewer samples when n is
+    far from a power of two; slightly different degree law) -- only for the one-off large-scale runs, the
+    test / bench graphs keep fold=False.
     Returns (src, dst) int32 arrays sorted by (src, dst).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -57,6 +60,9 @@ def rmat_graph(n, m, seed, dangling="none"):
     while extra.size < need:
         want = int((need - extra.size) * 1.3) + 1024
         s, d = _rmat_pairs(rng, scale, want)
+        if fold:
+            s %= n
+            d %= n
         ok = (s < n) & (d < n) & (s != d)
         k = perm[s[ok]] * n + perm[d[ok]]
         # keep first occurrences in generation order so truncation is unbiased
