@@ -40,6 +40,9 @@ struct fora_ctx {
     uint64_t *d_rowinfo = nullptr;
     uint32_t *d_deg = nullptr;
     uint32_t *d_rp32 = nullptr, *d_colp = nullptr;
+    int32_t *d_col_push = nullptr;  // row-sorted copy of col (multi-pass graphs whose rows are not sorted)
+    uint32_t *d_row_split = nullptr; // [n][npass + 1]
+    int split_pbins = 0;
     uint32_t colbits = 0;
 
     // params
@@ -122,7 +125,8 @@ template <typename T> void dfree(T *&p) {
 }
 
 void free_graph(fora_ctx *c) {
-    dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp);
+    dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
+    c->split_pbins = 0;
     c->n = 0; c->nnz = 0;
 }
 void free_index(fora_ctx *c) {
@@ -205,6 +209,43 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     return p;
 }
 
+// Multi-pass graphs (more bins than one pass holds): row-sorted copy of col + per-row split offsets, so that every
+// pass of k_pushq_popbin reads only its own part of each popped row.  Built once per (graph, pass size).
+int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
+    const int npass = pbins > 0 ? (nbins + pbins - 1) / pbins : 1;
+    if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
+    if (npass <= 1 || getenv("FORA_HIP_NO_SPLIT")) { dfree(c->d_col_push); dfree(c->d_row_split); c->split_pbins = 0; return FORA_OK; }
+    if (c->d_row_split && c->split_pbins == pbins) return FORA_OK;
+    dfree(c->d_col_push); dfree(c->d_row_split);
+    const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
+    std::vector<int32_t> col(std::max<size_t>(1, nnz));
+    if (nnz) HIPCHK(c, hipMemcpy(col.data(), c->d_col, nnz * 4, hipMemcpyDeviceToHost));
+    bool sorted = true;
+    for (size_t v = 0; v < n && sorted; v++)
+        for (int64_t e = c->h_row_ptr[v] + 1; e < c->h_row_ptr[v + 1]; e++)
+            if (col[(size_t)e - 1] > col[(size_t)e]) { sorted = false; break; }
+    if (!sorted) {
+        for (size_t v = 0; v < n; v++) std::sort(col.begin() + c->h_row_ptr[v], col.begin() + c->h_row_ptr[v + 1]);
+        HIPCHK(c, hipMalloc(&c->d_col_push, std::max<size_t>(1, nnz) * 4));
+        HIPCHK(c, hipMemcpy(c->d_col_push, col.data(), nnz * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<uint32_t> split(n * (size_t)(npass + 1));
+    for (size_t v = 0; v < n; v++) {
+        const int32_t *rb = col.data() + c->h_row_ptr[v], *re = col.data() + c->h_row_ptr[v + 1];
+        uint32_t *sp = split.data() + v * (size_t)(npass + 1);
+        sp[0] = 0;
+        for (int p = 1; p < npass; p++) {
+            const int64_t first_node = (int64_t)p * pbins * (int64_t)BIN_SIZE;
+            sp[p] = (uint32_t)(std::lower_bound(rb, re, (int32_t)std::min<int64_t>(first_node, INT32_MAX)) - rb);
+        }
+        sp[npass] = (uint32_t)(re - rb);
+    }
+    HIPCHK(c, hipMalloc(&c->d_row_split, split.size() * 4));
+    HIPCHK(c, hipMemcpy(c->d_row_split, split.data(), split.size() * 4, hipMemcpyHostToDevice));
+    c->split_pbins = pbins;
+    return FORA_OK;
+}
+
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     const WsPlan p = plan_workspace(c, omega_hint);
@@ -219,7 +260,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
     const uint64_t n = (uint64_t)c->n;
     const uint64_t scratch = (uint64_t)B * p.scratch;
-    if (c->B >= B && c->binned == p.binned && c->pbins == p.pbins && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return FORA_OK;
+    if (c->B >= B && c->binned == p.binned && c->pbins == p.pbins && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return ensure_row_split(c, p.nbins, p.pbins);
     free_workspace(c);
     const uint64_t slab = (uint64_t)B * n;
     HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
@@ -252,6 +293,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipHostMalloc(&c->h_steps_pin, sizeof(unsigned long long)));
     c->B = B;
     c->binned = p.binned; c->nbins = p.nbins; c->pbins = p.pbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
+    if (int rs = ensure_row_split(c, p.nbins, p.pbins)) return rs;
     c->wl_cap = slab;
     c->seg_cap = scratch / sizeof(PushSeg);
     c->wit_cap = p.wits; // per slot
@@ -284,6 +326,10 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.alpha = c->alpha; d.omega = omega; d.opt = c->opt;
     d.binned = c->binned ? 1 : 0; d.nbins = c->nbins; d.wide = c->binned && want_wide(c) ? 1 : 0;
     d.pbins = c->pbins; d.bin_lo = 0; d.bin_cnt = std::min(c->pbins, c->nbins);
+    d.col_push = c->d_col_push ? c->d_col_push : c->d_col;
+    d.row_split = c->d_row_split;
+    d.npass = c->pbins > 0 ? (c->nbins + c->pbins - 1) / c->pbins : 1;
+    d.pass = 0;
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
     d.inc_tab = c->d_inc_tab; d.segq_cap = c->segq_cap;
@@ -359,6 +405,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
+                dp.pass = lo / c->pbins;
                 int h = ev_begin(c, 1);
                 if (d.wide) hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 else hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
@@ -542,6 +589,7 @@ int sync_twin(fora_ctx *c) {
     w->n = c->n; w->m_attr = c->m_attr; w->nnz = c->nnz;
     w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
     w->d_rp32 = c->d_rp32; w->d_colp = c->d_colp; w->colbits = c->colbits;
+    w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;

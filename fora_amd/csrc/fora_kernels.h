@@ -108,6 +108,12 @@ struct Dev {
     int32_t binned, nbins;  // nbins: bins of the whole graph
     int32_t pbins;          // bins per pass = stride of the bucket arrays (<= MAX_BINS_WIDE)
     int32_t bin_lo, bin_cnt; // bins [bin_lo, bin_lo + bin_cnt) are handled by the current pass
+    // multi-pass graphs: a copy of col with every row sorted by target (the push sums over a row, order is
+    // free) and, per node, the offsets where each pass's target range starts -- a pass then reads only its own
+    // part of every popped row instead of the whole row
+    const int32_t *col_push;   // == col when there is one pass
+    const uint32_t *row_split; // [n][npass + 1] or null
+    int32_t npass, pass;
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
     uint64_t *inc_tab;      // [slot][segq_cap] increment of the node at frontier position i (gathered by k_accum)
@@ -513,6 +519,11 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
             const uint32_t v = in[i];
             int64_t beg; uint64_t deg;
             node_row(d, v, beg, deg);
+            if (d.row_split) { // only the part of the (sorted) row whose targets belong to this pass
+                const uint32_t *sp = d.row_split + (uint64_t)v * (d.npass + 1) + d.pass;
+                beg += sp[0];
+                deg = sp[1] - sp[0];
+            }
             s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = incs[i];
             cnt = (uint32_t)deg;
@@ -538,6 +549,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
             acc_res += res_add;
             acc_pops++;
             acc_relax += deg;
+            if (d.row_split) { // pass 0 of several: bin only the head of the sorted row
+                const uint32_t *sp = d.row_split + (uint64_t)v * (d.npass + 1);
+                deg = sp[1]; // sp[0] == 0
+            }
             s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = inc;
             incs[i] = inc;
@@ -571,7 +586,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
             for (int k = 0; k < BIN_EPT; k++) { // straight-line: all BIN_EPT gathers in flight together
                 const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
-                if (e < total) w[k] = (uint32_t)d.col[s_ebeg[si[k]] + (e - s_pref[si[k]])];
+                if (e < total) w[k] = (uint32_t)d.col_push[s_ebeg[si[k]] + (e - s_pref[si[k]])];
             }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {

@@ -244,11 +244,24 @@ def test_topk_argument_checks(engine, oracle, tiny):
 
 
 @pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow",
-                                  "bucketed_wide_multipass"])
+                                  "bucketed_wide_multipass", "bucketed_wide_multipass_unsorted",
+                                  "bucketed_wide_multipass_nosplit"])
 def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
     """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
     overflow fallback all give the twin's bits (integer adds commute)."""
     g = small_dangling
+    if mode == "bucketed_wide_multipass_unsorted":
+        # rows in arbitrary (file) order: the engine pushes over its own row-sorted copy, walks keep file order
+        from fora_amd import synth
+        n, m, seed = synth.PRESETS["small"]
+        src, dst = synth.rmat_graph(n, m, seed, "rmat")
+        perm = np.random.Generator(np.random.PCG64(99)).permutation(src.size)
+        g = oracle.Graph.from_edges(n, m, src[perm], dst[perm])
+        assert (np.diff(g.col[g.row_ptr[np.argmax(g.deg)]:g.row_ptr[np.argmax(g.deg) + 1]]) < 0).any()
+        mode = "bucketed_wide_multipass"
+    if mode == "bucketed_wide_multipass_nosplit":  # every pass scans whole rows and filters by bin range
+        monkeypatch.setenv("FORA_HIP_NO_SPLIT", "1")
+        mode = "bucketed_wide_multipass"
     if mode == "direct":
         monkeypatch.setenv("FORA_HIP_DIRECT", "1")
     elif mode == "bucketed_overflow":
@@ -280,6 +293,7 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         engine.clear_index()
     monkeypatch.delenv("FORA_HIP_FORCE_WIDE", raising=False)
     monkeypatch.delenv("FORA_HIP_PASS_BINS", raising=False)
+    monkeypatch.delenv("FORA_HIP_NO_SPLIT", raising=False)
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 

@@ -45,7 +45,7 @@ t0 = time.time()
 e.build_index()
 total, _, _ = e.index_sizes()
 print(f"index: {total} walks built in {time.time() - t0:.2f} s", flush=True)
-_, st = e.query(srcs[:2], with_idx=True, want_ppr=False)  # warm-up: allocates the workspace
+_, st = e.query(srcs, with_idx=True, want_ppr=False)  # warm-up: allocates the workspace for this batch size
 e.reset_timing()
 t0 = time.time()
 _, st = e.query(srcs, with_idx=True, want_ppr=False)
