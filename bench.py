@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="queries in flight per launch (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the L-inf check against GPU power iteration")
     ap.add_argument("--topk", type=int, default=0, help="k > 0: time `topk --opt` (config 5 style) instead of `query`")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-kernel FETCH_SIZE/WRITE_SIZE summary from separate rocprofv3 --pmc passes (tools/pmc_summary.py)")
@@ -71,6 +74,43 @@ def cpu_baseline(g, sources, rmax, omega, args, index):
                   f"{'indexed' if index is not None else 'online Philox'} walks, 1 thread, {dt:.1f} s",
         "walks_per_query": walks / max(1, done),
     }, ppops / max(1, pn), prelax / max(1, pn)
+
+
+def cpu_all_cores(g, sources, rmax, omega, args, index, threads):
+    """the same oracle on T host threads, sources sharded, private state per call
+    (ctypes releases the GIL around the C call)."""
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    budget = args.cpu_seconds
+
+    def work(tid):
+        done = 0
+        for s in sources[tid::threads]:
+            O.query(g, int(s), rmax, omega, opt=args.opt, seed=0x464F5241, index=index)
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        return done
+    with ThreadPoolExecutor(threads) as ex:
+        done = sum(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{done} of the bench sources over {threads} threads (sources tid mod T), {dt:.1f} s"}
+
+
+def accuracy(eng, sources, n, args, np):
+    """BASELINE metric, second half: L-inf PPR error.  Exact vector = fwd_power_iteration (query.h:1192-1224,
+    100 iterations) run on the GPU (fora_hip_power_iteration_batch, bit-checked against the twin in tests)."""
+    ns = min(len(sources), 8 if n <= 10_000_000 else 2)
+    est, _ = eng.query(sources[:ns], with_idx=args.with_idx)
+    exact, _, _, _ = eng.power_iteration(sources[:ns], max_iter=100)
+    err = np.abs(est - exact)
+    big = exact >= 1.0 / n
+    rel = float((err[big] / exact[big]).max()) if big.any() else 0.0
+    return {"sources": int(ns), "linf_abs_err": float(err.max()), "max_rel_err_where_pi_ge_1_over_n": rel,
+            "guarantee": f"rel err <= eps = {args.epsilon} for pi >= 1/n (algo.h:455-463)", "holds": bool(rel <= args.epsilon),
+            "exact": "GPU power iteration, 100 iterations (query.h:1192-1224)"}
 
 
 def main():
@@ -193,6 +233,11 @@ def main():
                 index = (rw, off, cnt)
             cpu, p_fifo, e_fifo = cpu_baseline(g, mine, rmax, omega, args, index)
             out["cpu_baseline"] = cpu
+            threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
+            if threads > 1:
+                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
+        if not args.no_accuracy and not args.opt:
+            out["accuracy"] = accuracy(eng, mine, n, args, np)
         # roofline of the dominant push kernel (k_push_expand): ALGORITHMIC bytes = 24 B per edge
         # relaxation of the sequential FIFO oracle; relaxations the level-synchronous
         # schedule adds on top are not credited.  Duration: HIP events around every launch.

@@ -15,7 +15,7 @@ SYMBOLS = [
     "fora_hip_set_graph", "fora_hip_set_params", "fora_hip_set_params_raw", "fora_hip_get_params",
     "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",
-    "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
+    "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
     "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing",
 ]
 
@@ -194,6 +194,20 @@ class Engine:
                                                 C.c_double(rmax_scale), C.c_int(int(with_idx)), _p(ids), _p(sc),
                                                 _p(rounds)))
         return ids, sc, rounds[:nq]
+
+    def power_iteration(self, sources, max_iter=100, k=0, want_ppr=True, want_fix=False):
+        """Exact SSPPR (gen_exact_topk's fwd_power_iteration, query.h:1192-1238).  Returns (ppr f64 [nq,n] or
+        None, ppr raw u64 or None, ids [nq,k] or None, scores or None)."""
+        src = np.ascontiguousarray(sources, dtype=np.int32)
+        nq = src.size
+        ppr = np.zeros((nq, self.n), dtype=np.float64) if want_ppr else None
+        fix = np.zeros((nq, self.n), dtype=np.uint64) if want_fix else None
+        ids = np.zeros((nq, k), dtype=np.int32) if k else None
+        sc = np.zeros((nq, k), dtype=np.float64) if k else None
+        self._chk(self._lib.fora_hip_power_iteration_batch(
+            self._ctx, _p(src), C.c_int(nq), C.c_int(max_iter), _p(ppr) if want_ppr else None,
+            _p(fix) if want_fix else None, C.c_int(k), _p(ids) if k else None, _p(sc) if k else None))
+        return ppr, fix, ids, sc
 
     # ---- stage hooks
     def walk_counts(self, residue, rsum):

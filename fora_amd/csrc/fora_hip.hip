@@ -390,7 +390,7 @@ int check_dev_err(fora_ctx *c) {
 // Level loop of the push for the slots already initialised (level-0 frontier in place).
 // Launches run ahead of the host by SPEC levels: an empty level costs a few near-empty
 // launches, a host round trip per level would cost more.
-int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
+int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, int level_cap = 0) {
     hipEvent_t done[SPEC + 1];
     for (auto &e : done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int rc = FORA_OK;
@@ -399,6 +399,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr) {
     unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
     if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
     for (;; L++) {
+        if (level_cap > 0 && L >= level_cap) break; // power iteration: a fixed number of levels
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
         if (c->binned) {
             for (int lo = 0; lo < c->nbins; lo += c->pbins) { // one pass per group of pbins bins (usually one)
@@ -1115,6 +1116,62 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             c->timing.idx_hits += c->h_qs[i].n_hit;
         }
         if (rounds) for (int i = 0; i < nb; i++) rounds[b0 + i] = nround[i];
+    }
+    return FORA_OK;
+}
+
+// gen_exact_topk's kernel (query.h:1192-1238): the push with threshold = one unit per out-edge and a fixed
+// number of levels; what it reserves is the exact PPR up to (1-alpha)^max_iter.
+int fora_hip_power_iteration_batch(fora_ctx *c, const int32_t *sources, int nq, int max_iter, double *ppr_out,
+                                   uint64_t *ppr_fix_out, int k, int32_t *ids, double *scores) {
+    if (!c) return FORA_E_ARG;
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha)");
+    if (nq < 0 || (nq && !sources) || max_iter < 1 || max_iter >= MAX_LEVELS) return fail(c, FORA_E_ARG, "bad arguments");
+    const bool want_topk = ids || scores;
+    if (want_topk && (!ids || !scores || k < 1 || k > SEL_MAXK || k > c->n)) return fail(c, FORA_E_ARG, "bad k / ids / scores");
+    for (int i = 0; i < nq; i++)
+        if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_workspace(c, nq, c->omega);
+    if (rc) return rc;
+    const uint64_t n = (uint64_t)c->n;
+    if (want_topk && c->topk_cap < c->B * k) {
+        dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+        HIPCHK(c, hipMalloc(&c->d_topk_ids, (size_t)c->B * k * 4));
+        HIPCHK(c, hipMalloc(&c->d_topk_sc, (size_t)c->B * k * 8));
+        c->topk_cap = c->B * k;
+    }
+    for (int b0 = 0; b0 < nq; b0 += c->B) {
+        const int nb = std::min(c->B, nq - b0);
+        const int hb = ev_begin(c, 5);
+        rc = reset_batch_state(c, nb, sources + b0);
+        if (rc) return rc;
+        Dev d = make_dev(c, nb, false, 0.0, c->omega); // rmax 0 -> threshold of one unit per out-edge
+        hipLaunchKernelGGL(k_init_batch, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 2);
+        rc = run_push_levels(c, d, nullptr, max_iter);
+        if (rc) return rc;
+        if (want_topk) {
+            int h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, d, k, c->d_topk_ids, c->d_topk_sc);
+            ev_end(c, h);
+            HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(scores + (size_t)b0 * k, c->d_topk_sc, (size_t)nb * k * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        ev_end(c, hb);
+        rc = check_dev_err(c);
+        if (rc) return rc;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("power iteration: ") + hipGetErrorString(e));
+        ev_collect(c);
+        const uint64_t bytes = (uint64_t)nb * n * 8;
+        if (ppr_fix_out) HIPCHK(c, hipMemcpy(ppr_fix_out + (uint64_t)b0 * n, c->d_ppr, bytes, hipMemcpyDeviceToHost));
+        if (ppr_out) {
+            double *dst = ppr_out + (uint64_t)b0 * n;
+            HIPCHK(c, hipMemcpy(dst, c->d_ppr, bytes, hipMemcpyDeviceToHost));
+            uint64_t *raw = (uint64_t *)dst;
+            for (uint64_t i = 0; i < (uint64_t)nb * n; i++) dst[i] = std::ldexp((double)raw[i], -62);
+        }
     }
     return FORA_OK;
 }

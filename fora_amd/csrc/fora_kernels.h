@@ -281,20 +281,22 @@ __device__ __forceinline__ uint64_t walk_count(double residual, double check_rsu
 
 // ------------------------------------------------------------------ init
 // residue[s] = 1, frontier = {s} (algo.h:969-978); dangling source: reserve[s] = 1 (algo.h:961-965)
-__global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int topk_mode) {
+// mode 0: query, 1: top-k (round frontier built by k_topk_frontier), 2: power iteration (no dangling-source
+// short cut: query.h:1192-1224 iterates it like any other node)
+__global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
     int q = blockIdx.x * BLOCK + threadIdx.x;
     if (q >= d.nq) return;
     QState z = {};
     const uint32_t s = (uint32_t)d.src[q];
     int64_t beg; uint64_t deg;
     node_row(d, s, beg, deg);
-    if (deg == 0) {
+    if (deg == 0 && mode != 2) {
         d.ppr[(uint64_t)q * d.n + s] = FIX_ONE;
         z.reserved = FIX_ONE;
         z.dangling_source = 1;
     } else {
         d.residue[(uint64_t)q * d.n + s] = FIX_ONE;
-        if (!topk_mode) {
+        if (mode != 1) {
             if (d.binned) {
                 d.fl[0][(uint64_t)q * d.n] = s;
                 d.fl_count[0][q * CSTRIDE] = 1;
@@ -1132,7 +1134,7 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
 // A wave collects (dest, weight) pairs in its own LDS area; when the area is nearly full it
 // bins them by target range (LDS counters), reserves bucket space with ONE global atomic per
 // (flush, bin), and stores them.  k_accum then reduces every (slot, bin) bucket in LDS.
-constexpr int STAGE = 512; // pairs per wave
+constexpr int STAGE = 256; // pairs per wave (512: 4 workgroups per CU by LDS; 256 + the register cap below: 5, 2-3 % faster)
 struct WaveStage {
     uint32_t *dest;  // [STAGE]
     uint64_t *wgt;   // [STAGE]
@@ -1344,7 +1346,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
 // for the longest walk of the wave.  Walks start on even iterations only, hence all running
 // walks of a wave share step parity and the Philox call (one per two steps) is wave-uniform.
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_walk_online(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_walk_online(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
     const int q = blockIdx.y;

@@ -21,6 +21,7 @@ static const char *const QUERY = "query";
 static const char *const GEN_SS_QUERY = "generate-ss-query";
 static const char *const TOPK = "topk";
 static const char *const BUILD = "build";
+static const char *const GEN_EXACT_TOPK = "gen-exact-topk"; // config.h:37
 static const char *const CHECK_GRAPH = "check-graph"; // not in the reference: loader self-check
 static const char *const FORA = "fora";
 
@@ -45,6 +46,7 @@ struct Config { // config.h:86-160
     double alpha = 0.2;            // config.h:27,132
     std::string exact_pprs_folder;
     unsigned int hub_space_consum = 1;
+    unsigned int max_iter_num = 100; // config.h:115
     // MI355X additions (not in the reference)
     uint64_t seed = 0x464F5241ull;
     int device = 0;
@@ -60,6 +62,10 @@ struct Result { // config.h:162-232
     double num_randwalk = 0, num_rw_idx_use = 0, hit_idx_ratio = 0;
     double randwalk_time = 0, randwalk_time_ratio = 0, propagation_time = 0, propagation_time_ratio = 0;
     double topk_sort_time = 0;
+    // config.h:188-196; the four error sums are never written by the reference either
+    double topk_max_abs_err = 0, topk_avg_abs_err = 0, topk_max_relative_err = 0, topk_avg_relative_err = 0;
+    double topk_precision = 0, topk_recall = 0;
+    int real_topk_source_count = 0;
 };
 
 // "name=value" line on stdout like INFO(...) (mylib.h:557-559, mylib.cpp:11-21)
@@ -166,7 +172,14 @@ inline std::string save_json(Config &c, const Result &r, const Timers &t, const 
     f << "        \"total time ratio on propagation(%)\": " << jnum(r.propagation_time_ratio) << ",\n";
     f << "        \"total number of rand-walks\": " << jnum(r.num_randwalk) << ",\n";
     f << "        \"total number of rand-walk idx used\": " << jnum(r.num_rw_idx_use) << ",\n";
-    f << "        \"total usage ratio of rand-walk idx\": " << jnum(r.hit_idx_ratio) << "\n";
+    f << "        \"total usage ratio of rand-walk idx\": " << jnum(r.hit_idx_ratio) << ",\n";
+    const double cnt = (double)r.real_topk_source_count; // config.h:223-228 divide by it unguarded: nan when no source had ground truth
+    f << "        \"topk max absolute error\": " << jnum(r.topk_max_abs_err / cnt) << ",\n";
+    f << "        \"topk avg absolute error\": " << jnum(r.topk_avg_abs_err / cnt) << ",\n";
+    f << "        \"topk max relative error\": " << jnum(r.topk_max_relative_err / cnt) << ",\n";
+    f << "        \"topk avg relative error\": " << jnum(r.topk_avg_relative_err / cnt) << ",\n";
+    f << "        \"topk precision\": " << jnum(r.topk_precision / cnt) << ",\n";
+    f << "        \"topk recall\": " << jnum(r.topk_recall / cnt) << "\n";
     f << "    },\n";
     f << "    \"timer\": {\n";
     bool first = true;

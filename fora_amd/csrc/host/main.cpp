@@ -11,7 +11,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <thread>
 
 using namespace forahost;
@@ -38,6 +42,7 @@ static const char *HELP =
     "fora query --algo <algo> [options]\n"
     "fora topk  --algo <algo> [options]\n"
     "fora build [options]\n"
+    "fora gen-exact-topk [options]\n"
     "fora generate-ss-query [options]\n"
     "fora\n"
     "\n"
@@ -71,6 +76,12 @@ static void finish(const Graph &graph, int used_counter, unsigned query_size, do
     cout << timers.get(FWD_LU) * 100.0 / tot << "%" << " for forward push cost" << endl;
     split_line();
     if (config.with_rw_idx) cout << "Average rand-walk idx hit ratio: " << n_hit * 100.0 / n_walks << "%" << endl;
+    if (config.action == TOPK) { // algo.h:394-398; the reference asserts when no source had ground truth
+        if (result.real_topk_source_count > 0) {
+            cout << "Average top-K Precision: " << result.topk_precision / result.real_topk_source_count << endl;
+            cout << "Average top-K Recall: " << result.topk_recall / result.real_topk_source_count << endl;
+        } else cout << "no exact top-k file (fora gen-exact-topk): precision / recall not evaluated" << endl;
+    }
     cout << "Average query time (s):" << tot / query_size << endl;
     cout << "Memory usage (MB):" << proc_memory_mb() << endl << endl;
     config.query_size = query_size;
@@ -85,6 +96,83 @@ static void finish(const Graph &graph, int used_counter, unsigned query_size, do
     result.propagation_time = timers.get(FWD_LU);
     result.propagation_time_ratio = timers.get(FWD_LU) * 100 / tot;
     if (config.action == TOPK) result.topk_sort_time = timers.get(SORT_MAP);
+}
+
+// ---- ground truth for top-k: exact_topk_pprs (algo.h:45), <exact_pprs_folder>/<dataset>.topk.pprs (build.h:121-125).
+// The reference stores the map as a Boost text archive; this build keeps the file name and writes one line per
+// source: "<source> <count> <id>:<score> ..." under a one-line header.
+using ExactTopk = std::map<int32_t, std::vector<std::pair<int32_t, double>>>;
+static ExactTopk exact_topk_pprs;
+
+static string exact_topk_file() {
+    if (config.exact_pprs_folder.empty() || config.exact_pprs_folder.back() != '/') config.exact_pprs_folder += "/";
+    return config.exact_pprs_folder + config.graph_alias + ".topk.pprs";
+}
+static bool file_exists(const string &f) {
+    if (FILE *t = fopen(f.c_str(), "r")) { fclose(t); return true; }
+    return false;
+}
+static bool save_exact_topk(const string &f) { // save_exact_topk_ppr, build.h:127-132
+    FILE *fo = fopen(f.c_str(), "w");
+    if (!fo) return false;
+    fprintf(fo, "fora-exact-topk 1 %zu\n", exact_topk_pprs.size());
+    for (auto &kv : exact_topk_pprs) {
+        fprintf(fo, "%d %zu", kv.first, kv.second.size());
+        for (auto &p : kv.second) fprintf(fo, " %d:%.17g", p.first, p.second);
+        fprintf(fo, "\n");
+    }
+    return fclose(fo) == 0;
+}
+static void load_exact_topk() { // load_exact_topk_ppr, build.h:134-145
+    const string f = exact_topk_file();
+    if (!file_exists(f)) { info("No exact topk ppr file", f); return; }
+    FILE *fi = fopen(f.c_str(), "r");
+    char tag[32] = {0};
+    int ver = 0;
+    size_t count = 0;
+    if (!fi || fscanf(fi, "%31s %d %zu", tag, &ver, &count) != 3 || string(tag) != "fora-exact-topk" || ver != 1) {
+        cerr << f << " is not a fora-exact-topk v1 file (Boost text archives of the reference are not readable here)" << endl;
+        if (fi) fclose(fi);
+        return;
+    }
+    for (size_t i = 0; i < count; i++) {
+        int src;
+        size_t len;
+        if (fscanf(fi, "%d %zu", &src, &len) != 2) break;
+        auto &v = exact_topk_pprs[src];
+        v.resize(len);
+        for (size_t j = 0; j < len; j++)
+            if (fscanf(fi, "%d:%lf", &v[j].first, &v[j].second) != 2) { v.resize(j); break; }
+    }
+    fclose(fi);
+    info("exact_topk_pprs.size()", exact_topk_pprs.size());
+}
+
+// compute_precision, algo.h:524-572 (both ratios are over the size of the exact set, as in the reference)
+static void compute_precision(int32_t v, const int32_t *ids, const double *scores, unsigned k) {
+    auto it = exact_topk_pprs.find(v);
+    if (exact_topk_pprs.empty() || it == exact_topk_pprs.end()) return;
+    std::unordered_set<int32_t> topk_set, exact_set;
+    for (unsigned i = 0; i < k; i++)
+        if (scores[i] > 0) topk_set.insert(ids[i]);
+    double recall = 0, precision = 0;
+    const size_t size_e = std::min<size_t>(k, it->second.size());
+    for (size_t i = 0; i < size_e; i++) {
+        const auto &p = it->second[i];
+        if (p.second > 0) {
+            exact_set.insert(p.first);
+            if (topk_set.count(p.first)) recall++;
+        }
+    }
+    for (int32_t id : topk_set)
+        if (exact_set.count(id)) precision++;
+    if (exact_set.empty() || topk_set.empty()) return; // the reference asserts here (algo.h:559-560)
+    recall /= (double)exact_set.size();
+    precision /= (double)exact_set.size();
+    cout << "exact_map.size()=" << exact_set.size() << " recall=" << recall << " precision=" << precision << endl;
+    result.topk_recall += recall;
+    result.topk_precision += precision;
+    result.real_topk_source_count++;
 }
 
 static int open_engine(const Graph &graph, fora_ctx **ctx, int device = -1) {
@@ -225,6 +313,7 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
             return 1;
         }
     }
+    load_exact_topk(); // query.h:1323
     std::vector<int32_t> ids((size_t)query_size * config.k), rounds(query_size);
     std::vector<double> scores((size_t)query_size * config.k);
     std::vector<Shard> shards;
@@ -254,6 +343,7 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     for (unsigned i = 0; i < query_size; i++) {
         cout << i + 1 << ". source node:" << queries[i] << endl; // query.h:1398
         num_iter_topk += rounds[i];
+        compute_precision(queries[i], &ids[(size_t)i * config.k], &scores[(size_t)i * config.k], config.k); // query.h:1180
         if (fo) {
             fprintf(fo, "%d", queries[i]);
             for (unsigned j = 0; j < config.k; j++) fprintf(fo, " %d:%.17g", ids[(size_t)i * config.k + j], scores[(size_t)i * config.k + j]);
@@ -267,6 +357,55 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     timers.add(0, timers.get(FORA_QUERY));
     finish(graph, FORA_QUERY, query_size, tot_walks, tot_hits);
     cout << "top-k lists written to " << out << endl;
+    return 0;
+}
+
+static int do_gen_exact_topk(Graph &graph) { // gen_exact_topk(), query.h:1240-1307
+    std::vector<int32_t> queries;
+    if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); }
+    info("queries.size()", queries.size());
+    unsigned query_size = std::min<unsigned>((unsigned)queries.size(), config.query_size);
+    info("query_size", query_size);
+    const string f = exact_topk_file();
+    if (file_exists(f)) { puts("exact top k exists"); return 0; } // query.h:1251-1254
+    if (!(config.k < (unsigned)graph.n - 1) || !(config.k > 1)) { cerr << "k out of range" << endl; return 1; } // :1255-1256
+    if (config.k > 1024) { cerr << "k > 1024 not supported" << endl; return 1; }
+    info("config.k", config.k);
+    split_line();
+    puts("power itrating...");
+    if (!(config.epsilon > 0)) config.epsilon = 0.5; // not used by the iteration; the engine wants a valid parameter set
+    const size_t k = config.k;
+    std::vector<int32_t> ids((size_t)query_size * k);
+    std::vector<double> scores((size_t)query_size * k);
+    std::vector<Shard> shards;
+    // multi_power_iter (query.h:1226-1238) threads over CPU cores; here sources i mod G over the GPUs
+    if (run_sharded(graph, queries, query_size, nullptr, shards, [&](fora_ctx *ctx, Shard &s) {
+            const size_t nl = s.sources.size();
+            std::vector<int32_t> lid(nl * k);
+            std::vector<double> lsc(nl * k);
+            if (fora_hip_power_iteration_batch(ctx, s.sources.data(), (int)nl, (int)config.max_iter_num, nullptr, nullptr, (int)k,
+                                               lid.data(), lsc.data()))
+                return 1;
+            for (size_t i = 0; i < nl; i++) {
+                std::copy(lid.begin() + (long)(i * k), lid.begin() + (long)((i + 1) * k), ids.begin() + (long)(s.pos[i] * k));
+                std::copy(lsc.begin() + (long)(i * k), lsc.begin() + (long)((i + 1) * k), scores.begin() + (long)(s.pos[i] * k));
+            }
+            return 0;
+        }))
+        return 1;
+    double wall = 0;
+    for (auto &s : shards) wall = std::max(wall, s.seconds);
+    timers.add(10, wall); // PI_QUERY, config.h:57
+    cout << "average generation time (s): " << wall / query_size << endl; // query.h:1294
+    puts("combine results...");
+    for (unsigned i = 0; i < query_size; i++) {
+        auto &v = exact_topk_pprs[queries[i]];
+        v.resize(k);
+        for (size_t j = 0; j < k; j++) v[j] = {ids[(size_t)i * k + j], scores[(size_t)i * k + j]};
+    }
+    make_dirs(config.exact_pprs_folder);
+    if (!save_exact_topk(f)) { cerr << "cannot write " << f << endl; return 1; }
+    cout << "exact top-k lists written to " << f << endl;
     return 0;
 }
 
@@ -343,7 +482,7 @@ int main(int argc, char *argv[]) {
     if (config.balanced) { cerr << "--balanced (wall-clock driven rmax, query.h:848-884) is not supported" << endl; return 1; }
 
     const string act = config.action;
-    if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH) {
+    if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH && act != GEN_EXACT_TOPK) {
         cerr << "sub command not regoznized" << endl; // fora.cpp:278-281
         return 1;
     }
@@ -365,6 +504,10 @@ int main(int argc, char *argv[]) {
     info("graph.n", graph.n);
     info("graph.m", graph.m);
 
+    { // fora.cpp:211-212, 254-255
+        struct stat sb;
+        if (config.exact_pprs_folder.empty() || stat(config.exact_pprs_folder.c_str(), &sb) != 0) config.exact_pprs_folder = config.graph_location;
+    }
     int rc = 0;
     if (act == CHECK_GRAPH) {
         uint64_t h = 1469598103934665603ull;
@@ -384,6 +527,7 @@ int main(int argc, char *argv[]) {
         return 0;
     } else if (act == QUERY) rc = do_query(graph);
     else if (act == TOPK) rc = do_topk(graph);
+    else if (act == GEN_EXACT_TOPK) rc = do_gen_exact_topk(graph);
     else if (act == BUILD) { const double t0 = now_s(); rc = do_build(graph); timers.add(0, now_s() - t0); }
     if (rc) return rc;
     timers.show(); // fora.cpp:282

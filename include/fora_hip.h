@@ -126,6 +126,16 @@ int fora_hip_topk_batch(fora_ctx *ctx, const int32_t *sources, int nq, int k, do
                         double rmax_scale, int with_idx, int32_t *ids, double *scores,
                         int32_t *rounds /*nq or NULL*/);
 
+/* ---- exact SSPPR: replaces fwd_power_iteration / multi_power_iter under gen_exact_topk
+ * (query.h:1192-1238, 1240-1307): max_iter Jacobi iterations (config.max_iter_num, config.h:115 = 100) of
+ * "keep alpha of every positive residual, push the rest along the out-edges, dangling mass back to the
+ * source", run as the level-synchronous push with the smallest threshold (one 2^-62 unit per out-edge).
+ * Any of ppr_out (nq*n doubles), ppr_fix_out (nq*n raw) and ids/scores (nq*k, k >= 1, score descending,
+ * ties id ascending, padded with (0, 0.0)) may be NULL. */
+int fora_hip_power_iteration_batch(fora_ctx *ctx, const int32_t *sources, int nq, int max_iter,
+                                   double *ppr_out, uint64_t *ppr_fix_out, int k, int32_t *ids,
+                                   double *scores);
+
 /* ---- stage hooks (same device code as the paths above, exposed for parity tests) */
 /* forward push only (forward_local_update_linear, algo.h:954-1018) */
 int fora_hip_push_batch(fora_ctx *ctx, const int32_t *sources, int nq, uint64_t *reserve_fix_out,

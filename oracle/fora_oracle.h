@@ -128,6 +128,9 @@ typedef struct {
 int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
                   double alpha, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *st,
                   int64_t *level_sizes, int64_t cap);
+/* fwd_power_iteration (query.h:1192-1224) in the twin's arithmetic; ppr: n u64 */
+int orc_twin_power_iteration(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double alpha,
+                             int32_t max_iter, uint64_t *ppr, orc_twin_push_stats *st);
 uint64_t orc_twin_walk_counts(int32_t n, const uint64_t *residue, uint64_t rsum_fix, double omega,
                               double alpha, int opt, uint64_t *num_s_rw);
 int orc_twin_refine(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s,

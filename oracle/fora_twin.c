@@ -56,8 +56,8 @@ void orc_fix_to_double(const uint64_t *in, int64_t n, double *out) {
 static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, uint64_t t1,
                         uint64_t afix, uint64_t *residue, uint64_t *reserve, int32_t *frontier,
                         int64_t fn, int32_t *next, uint64_t *inc, orc_twin_push_stats *st,
-                        int64_t *level_sizes, int64_t cap) {
-    while (fn > 0) {
+                        int64_t *level_sizes, int64_t cap, int64_t max_levels) {
+    while (fn > 0 && (max_levels <= 0 || st->levels < max_levels)) {
         if (level_sizes && st->levels < cap) level_sizes[st->levels] = fn;
         st->levels++;
         uint64_t dang = 0;
@@ -124,12 +124,34 @@ int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t
     residue[s] = ORC_FIX_ONE; /* algo.h:976 */
     frontier[0] = s;          /* the source is pushed unconditionally (algo.h:973,980) */
     twin_levels(row_ptr, col, s, orc_twin_rmax_fix(rmax), orc_twin_alpha_fix(alpha), residue, ppr,
-                frontier, 1, next, inc, &z, level_sizes, cap);
+                frontier, 1, next, inc, &z, level_sizes, cap, 0);
     uint64_t reserved = 0;
     for (int32_t v = 0; v < n; v++) reserved += ppr[v];
     z.rsum_fix = ORC_FIX_ONE - reserved; /* == sum of residue, exactly */
     if (st) *st = z;
     free(frontier); free(next); free(inc);
+    return 0;
+}
+
+/* Twin of fwd_power_iteration (query.h:1192-1224): max_iter levels of the same push with the smallest
+ * threshold (one unit per out-edge) and no dangling-source short cut; ppr = what was reserved. */
+int orc_twin_power_iteration(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double alpha,
+                             int32_t max_iter, uint64_t *ppr, orc_twin_push_stats *st) {
+    orc_twin_push_stats z = {0, 0, 0, 0};
+    uint64_t *residue = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    int32_t *frontier = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    memset(ppr, 0, sizeof(uint64_t) * (size_t)n);
+    residue[s] = ORC_FIX_ONE;
+    frontier[0] = s;
+    twin_levels(row_ptr, col, s, 1, orc_twin_alpha_fix(alpha), residue, ppr, frontier, 1, next, inc, &z, NULL, 0,
+                max_iter);
+    uint64_t reserved = 0;
+    for (int32_t v = 0; v < n; v++) reserved += ppr[v];
+    z.rsum_fix = ORC_FIX_ONE - reserved;
+    if (st) *st = z;
+    free(residue); free(frontier); free(next); free(inc);
     return 0;
 }
 
@@ -253,7 +275,7 @@ int orc_twin_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int3
         for (int32_t v = 0; v < n; v++)
             if (residue[v] >= node_thr(t1, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
         orc_twin_push_stats ps = {0, 0, 0, 0};
-        twin_levels(row_ptr, col, s, t1, afix, residue, reserve, frontier, fn, next, inc, &ps, NULL, 0);
+        twin_levels(row_ptr, col, s, t1, afix, residue, reserve, frontier, fn, next, inc, &ps, NULL, 0, 0);
         uint64_t reserved = 0;
         for (int32_t v = 0; v < n; v++) reserved += reserve[v];
         uint64_t rsum_fix = ORC_FIX_ONE - reserved;

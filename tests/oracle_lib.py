@@ -251,6 +251,14 @@ def twin_push(g, s, rmax, alpha=0.2, max_levels=1 << 16):
                 relax=st.relax, level_sizes=lv[:min(st.levels, max_levels)].copy())
 
 
+def twin_power_iteration(g, s, max_iter=100, alpha=0.2):
+    ppr = np.zeros(g.n, dtype=np.uint64)
+    st = TwinPushStats()
+    lib().orc_twin_power_iteration(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), C.c_int32(s), _d(alpha),
+                                   C.c_int32(max_iter), _p(ppr), C.byref(st))
+    return ppr, dict(rsum_fix=st.rsum_fix, levels=st.levels, pops=st.pops, relax=st.relax)
+
+
 def twin_walk_counts(g, residue, rsum_fix, omega, alpha=0.2, opt=False):
     out = np.zeros(g.n, dtype=np.uint64)
     N = lib().orc_twin_walk_counts(C.c_int32(g.n), _p(residue), C.c_uint64(rsum_fix), _d(omega), _d(alpha),

@@ -144,3 +144,56 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
     # topk without --opt is the bounds variant: refused, not silently substituted
     r = _run([cli, "topk", "--algo", "fora", "--k", "20", *common])
     assert r.returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_gen_exact_topk_and_precision(cli, oracle, small, tmp_path):
+    """gen-exact-topk (query.h:1240-1307) writes the ground truth next to the graph; a later `topk` evaluates
+    compute_precision (algo.h:524-572) against it and reports it like the reference (algo.h:394-398, config.h:227-228)."""
+    from conftest import pick_sources
+    g = small
+    queries = pick_sources(g, 6, 43)
+    folder = tmp_path / "data" / "g32k"
+    _write_dataset(str(folder), g, queries)
+    common = ["--prefix", str(tmp_path / "data") + "/", "--dataset", "g32k", "--result_dir", str(tmp_path / "res")]
+    k = 20
+    # topk before any ground truth exists: runs, says so (the reference would hit assert algo.h:395)
+    r = _run([cli, "topk", "--algo", "fora", "--opt", "--epsilon", "0.5", "--k", str(k), "--query_size", "4", *common])
+    assert r.returncode == 0, r.stderr
+    assert "precision / recall not evaluated" in r.stdout
+    r = _run([cli, "gen-exact-topk", "--k", str(k), "--query_size", "4", *common])
+    assert r.returncode == 0, r.stderr
+    assert "average generation time (s):" in r.stdout
+    f = folder / "g32k.topk.pprs"                                       # build.h:121-125
+    lines = open(f).read().strip().split("\n")
+    assert lines[0] == "fora-exact-topk 1 4"
+    want = {}
+    for s in queries[:4]:
+        fix, _ = oracle.twin_power_iteration(g, int(s), max_iter=100)
+        nz = np.flatnonzero(fix)
+        order = nz[np.lexsort((nz, -(fix[nz].astype(np.int64))))][:k]
+        want[int(s)] = (order.tolist(), oracle.fix_to_double(fix[order]).tolist())
+    for ln in lines[1:]:
+        tok = ln.split()
+        ids, sc = want[int(tok[0])]
+        assert int(tok[1]) == k
+        assert [int(x.split(":")[0]) for x in tok[2:]] == ids
+        assert [float(x.split(":")[1]) for x in tok[2:]] == sc
+    r2 = _run([cli, "gen-exact-topk", "--k", str(k), "--query_size", "4", *common])
+    assert r2.returncode == 0 and "exact top k exists" in r2.stdout     # query.h:1251-1254
+    r = _run([cli, "topk", "--algo", "fora", "--opt", "--epsilon", "0.5", "--k", str(k), "--query_size", "4", *common])
+    assert r.returncode == 0, r.stderr
+    assert "Average top-K Precision:" in r.stdout and "Average top-K Recall:" in r.stdout
+    # recompute compute_precision from the two files
+    got = open(tmp_path / "res" / f"g32k.topk.k-{k}.txt").read().strip().split("\n")
+    prec = rec = 0.0
+    for ln in got:
+        tok = ln.split()
+        est = {int(x.split(":")[0]) for x in tok[1:] if float(x.split(":")[1]) > 0}
+        ex = set(want[int(tok[0])][0])
+        rec += len(est & ex) / len(ex)
+        prec += len(est & ex) / len(ex)
+    j = json.load(open(tmp_path / "res" / "execution" / f"g32k.topk.fora.without_idx.k-{k}.rmax-1.000000.json"))
+    assert abs(float(j["result"]["topk precision"]) - prec / 4) < 1e-12
+    assert abs(float(j["result"]["topk recall"]) - rec / 4) < 1e-12
+    assert float(j["result"]["topk precision"]) >= 0.8

@@ -310,3 +310,37 @@ def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
     engine.set_batch(0)
     assert (a == b).all() and (ra == rb).all()
     assert all(s["ppr_sum_fix"] == oracle.FIX_ONE for s in st)
+
+
+@pytest.mark.parametrize("gname", ["tiny_dangling", "small", "small_dangling"])
+def test_power_iteration_bit_exact_vs_twin(engine, oracle, request, gname):
+    """Exact SSPPR (gen_exact_topk's fwd_power_iteration, query.h:1192-1238) on the GPU: the level-capped push
+    equals the twin bit for bit, agrees with the f64 restatement to 1e-12, and its top-k is the sorted head."""
+    g = request.getfixturevalue(gname)
+    _load(engine, g, epsilon=0.5)
+    srcs = np.concatenate([pick_sources(g, 5, 81), pick_sources(g, 2, 82, want_dangling=True)])
+    k = 50
+    for iters in (100, 7):
+        ppr, fix, ids, sc = engine.power_iteration(srcs, max_iter=iters, k=k, want_fix=True)
+        for i, s in enumerate(srcs):
+            want, st = oracle.twin_power_iteration(g, int(s), max_iter=iters)
+            assert (fix[i] == want).all()
+            assert (ppr[i] == oracle.fix_to_double(want)).all()
+            nz = np.flatnonzero(want)
+            order = nz[np.lexsort((nz, -(want[nz].astype(np.int64))))] if nz.size else nz
+            head = order[:k]
+            assert (ids[i][:head.size] == head).all()
+            assert (sc[i][:head.size] == oracle.fix_to_double(want[head])).all()
+            assert (ids[i][head.size:] == 0).all() and (sc[i][head.size:] == 0).all()
+        if iters == 100:
+            for i, s in enumerate(srcs[:3]):
+                assert np.abs(ppr[i] - oracle.power_iteration(g, int(s), iters=100)).max() < 1e-12
+    # the FORA answer honours its guarantee against this exact vector: |est - pi| <= eps * pi for pi >= 1/n
+    est, _ = engine.query(srcs[:4])
+    exact, _, _, _ = engine.power_iteration(srcs[:4], max_iter=100)
+    for i in range(4):
+        big = exact[i] >= 1.0 / g.n
+        assert (np.abs(est[i][big] - exact[i][big]) <= 0.5 * exact[i][big]).all()
+    import fora_amd
+    with pytest.raises(fora_amd.ForaError):
+        engine.power_iteration(srcs[:1], max_iter=0)

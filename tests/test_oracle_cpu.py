@@ -192,3 +192,32 @@ def test_topk_families_agree(oracle, small):
             assert len(truth & set(ids.tolist())) >= k - 3
             assert len(truth & set(ids2.tolist())) >= k - 3
             assert np.abs(sc[0] - sc2[0]) / sc[0] < 0.05
+
+
+@pytest.mark.parametrize("gname", ["tiny", "tiny_dangling"])
+def test_power_iteration_families_agree(oracle, request, gname):
+    """fwd_power_iteration (query.h:1192-1224): the f64 restatement, the fixed-point twin (level-capped push with
+    the smallest threshold) and a dense numpy iteration give the same vector; dangling sources iterate too."""
+    g = request.getfixturevalue(gname)
+    srcs = list(pick_sources(g, 3, 71)) + list(pick_sources(g, 1, 72, want_dangling=True))
+    for s in srcs:
+        s = int(s)
+        want = oracle.power_iteration(g, s, iters=100)
+        fix, st = oracle.twin_power_iteration(g, s, max_iter=100)
+        got = oracle.fix_to_double(fix)
+        assert st["levels"] <= 100
+        assert int(fix.sum()) + st["rsum_fix"] == oracle.FIX_ONE           # mass is conserved exactly
+        assert np.abs(got - want).max() < 1e-12
+        assert abs(got.sum() - (1 - 0.8 ** 100)) < 1e-9                    # what 100 iterations reserve
+        # dense numpy restatement
+        r = np.zeros(g.n); r[s] = 1.0
+        p = np.zeros(g.n)
+        deg = g.deg.astype(np.float64)
+        rows = np.repeat(np.arange(g.n), g.deg)
+        for _ in range(100):
+            p += 0.2 * r
+            push = np.where(g.deg > 0, 0.8 * r / np.maximum(deg, 1), 0.0)
+            nxt = np.bincount(g.col, weights=push[rows], minlength=g.n)
+            nxt[s] += 0.8 * r[g.deg == 0].sum()
+            r = nxt
+        assert np.abs(p - want).max() < 1e-12
