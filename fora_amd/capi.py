@@ -15,7 +15,7 @@ SYMBOLS = [
     "fora_hip_set_graph", "fora_hip_set_params", "fora_hip_set_params_raw", "fora_hip_get_params",
     "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",
-    "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
+    "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_topk_bound_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
     "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing",
 ]
 
@@ -193,6 +193,18 @@ class Engine:
         self._chk(self._lib.fora_hip_topk_batch(self._ctx, _p(src), C.c_int(nq), C.c_int(k), C.c_double(epsilon),
                                                 C.c_double(rmax_scale), C.c_int(int(with_idx)), _p(ids), _p(sc),
                                                 _p(rounds)))
+        return ids, sc, rounds[:nq]
+
+    def topk_bound(self, sources, k, epsilon=0.5, rmax_scale=1.0, ppr_decay_alpha=0.77, with_idx=False):
+        """get_topk without --opt (top-k with bounds, query.h:909-969)."""
+        src = np.ascontiguousarray(sources, dtype=np.int32)
+        nq = src.size
+        ids = np.zeros((nq, k), dtype=np.int32)
+        sc = np.zeros((nq, k), dtype=np.float64)
+        rounds = np.zeros(max(1, nq), dtype=np.int32)
+        self._chk(self._lib.fora_hip_topk_bound_batch(self._ctx, _p(src), C.c_int(nq), C.c_int(k), C.c_double(epsilon),
+                                                      C.c_double(rmax_scale), C.c_double(ppr_decay_alpha),
+                                                      C.c_int(int(with_idx)), _p(ids), _p(sc), _p(rounds)))
         return ids, sc, rounds[:nq]
 
     def power_iteration(self, sources, max_iter=100, k=0, want_ppr=True, want_fix=False):

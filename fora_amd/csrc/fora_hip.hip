@@ -83,6 +83,14 @@ struct fora_ctx {
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
     uint8_t *d_active = nullptr;
     unsigned long long *d_above = nullptr;
+    // top-k with bounds: upper_bounds / lower_bounds (query.h:1350-1353), topk_filter marks, stop flags, walks of the round
+    double *d_upper = nullptr, *d_lower = nullptr;
+    uint8_t *d_filter = nullptr;
+    uint32_t *d_fail = nullptr;
+    unsigned long long *d_round_walks = nullptr;
+    double *d_lb_sc = nullptr;
+    int32_t *d_lb_ids = nullptr;
+    int lb_cap = 0;
     int32_t *d_topk_ids = nullptr;
     double *d_topk_sc = nullptr;
     int topk_cap = 0;
@@ -137,6 +145,8 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_residue); dfree(c->d_ppr); dfree(c->d_wl[0]); dfree(c->d_wl[1]); dfree(c->d_scratch);
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+    dfree(c->d_upper); dfree(c->d_lower); dfree(c->d_filter); dfree(c->d_fail); dfree(c->d_round_walks);
+    dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
@@ -523,7 +533,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
         const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
         h = ev_begin(c, 2);
         hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
-                           (const uint8_t *)nullptr, (uint64_t *)nullptr);
+                           (const uint8_t *)nullptr, (uint64_t *)nullptr, (unsigned long long *)nullptr);
         ev_end(c, h);
         launch_walks(c, d, nq, with_idx, 0u, c->opt ? 1 : 0);
     }
@@ -1078,7 +1088,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
             dw.ppr = c->d_ppr2;
             h = ev_begin(c, 2);
             hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
-                               (const uint8_t *)c->d_active, c->d_cursor);
+                               (const uint8_t *)c->d_active, c->d_cursor, (unsigned long long *)nullptr);
             ev_end(c, h);
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, with_idx ? 1 : 0);
             const double T = (1 + epsilon) * delta; // query.h:1030
@@ -1099,7 +1109,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
         Dev ds = make_dev(c, nb, false);
         ds.ppr = c->d_ppr2;
         int h = ev_begin(c, 4);
-        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc);
+        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc, 0);
         ev_end(c, h);
         ev_end(c, hb);
         HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1110,6 +1120,175 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
         ev_collect(c);
         HIPCHK(c, hipMemcpy(c->h_qs.data(), c->d_qs, (size_t)nb * sizeof(QState), hipMemcpyDeviceToHost));
         for (int i = 0; i < nb; i++) { // counters accumulated over all rounds of the slot
+            c->timing.pops += c->h_qs[i].pops;
+            c->timing.relax += c->h_qs[i].relax;
+            c->timing.walks += c->h_qs[i].n_walks;
+            c->timing.idx_hits += c->h_qs[i].n_hit;
+        }
+        if (rounds) for (int i = 0; i < nb; i++) rounds[b0 + i] = nround[i];
+    }
+    return FORA_OK;
+}
+
+// top-k with bounds: fora_query_topk_with_bound (query.h:909-969) for a batch of slots.  As in the --opt driver all
+// active slots share a round (delta halves per round), finished slots drop out.  zero_ppr_upper_bound (query.h:935,
+// :748) only ever feeds itself in the reference and is not kept.
+int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                              double ppr_decay_alpha, int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
+    if (!c) return FORA_E_ARG;
+    if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha, seed)");
+    if (nq < 0 || (nq && (!sources || !ids || !scores))) return fail(c, FORA_E_ARG, "bad arguments");
+    if (k < 2 || k >= c->n - 1) return fail(c, FORA_E_ARG, "k out of range (query.h:1317-1318)");
+    if (k > SEL_MAXK) return fail(c, FORA_E_ARG, "k > 1024 not supported");
+    if (!(epsilon > 0) || !(rmax_scale >= 0)) return fail(c, FORA_E_ARG, "bad epsilon / rmax_scale");
+    if (!(ppr_decay_alpha > 0 && ppr_decay_alpha < 1)) return fail(c, FORA_E_ARG, "bad ppr_decay_alpha");
+    if (with_idx && !c->have_index) return fail(c, FORA_E_ARG, "with_idx without an index");
+    for (int i = 0; i < nq; i++)
+        if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    const double min_delta = 1.0 / c->n;                                                                    // query.h:911
+    const double init_delta = 1.0 / 4;                                                                      // :912
+    const double threshold = (1.0 - ppr_decay_alpha) / pow(500, ppr_decay_alpha) / pow(c->n, 1 - ppr_decay_alpha); // :913
+    const double pfail = 1.0 / c->n / c->n / log(c->n);                                                     // :915
+    const double L = log(2 / pfail);
+    const long long m = c->m_attr;
+    const double omega_max = (2 + epsilon) * L / min_delta / epsilon / epsilon;
+    int rc = ensure_workspace(c, nq, omega_max);
+    if (rc) return rc;
+    const uint64_t n = (uint64_t)c->n;
+    const uint64_t slab = (uint64_t)c->B * n;
+    if (!c->d_ppr2) {
+        HIPCHK(c, hipMalloc(&c->d_ppr2, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_cursor, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_active, (size_t)c->B));
+        HIPCHK(c, hipMalloc(&c->d_above, (size_t)c->B * 8));
+    }
+    if (!c->d_upper) {
+        HIPCHK(c, hipMalloc(&c->d_upper, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_lower, slab * 8));
+        HIPCHK(c, hipMalloc(&c->d_filter, slab));
+        HIPCHK(c, hipMemset(c->d_filter, 0, slab));
+        HIPCHK(c, hipMalloc(&c->d_fail, (size_t)c->B * 4));
+        HIPCHK(c, hipMalloc(&c->d_round_walks, (size_t)c->B * 8));
+    }
+    if (c->topk_cap < c->B * k) {
+        dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+        HIPCHK(c, hipMalloc(&c->d_topk_ids, (size_t)c->B * k * 4));
+        HIPCHK(c, hipMalloc(&c->d_topk_sc, (size_t)c->B * k * 8));
+        c->topk_cap = c->B * k;
+    }
+    if (c->lb_cap < c->B * k) {
+        dfree(c->d_lb_ids); dfree(c->d_lb_sc);
+        HIPCHK(c, hipMalloc(&c->d_lb_ids, (size_t)c->B * k * 4));
+        HIPCHK(c, hipMalloc(&c->d_lb_sc, (size_t)c->B * k * 8));
+        c->lb_cap = c->B * k;
+    }
+    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    std::vector<uint8_t> active;
+    std::vector<unsigned long long> above;
+    std::vector<uint32_t> failv;
+    for (int b0 = 0; b0 < nq; b0 += c->B) {
+        const int nb = std::min(c->B, nq - b0);
+        const int hb = ev_begin(c, 5);
+        rc = reset_batch_state(c, nb, sources + b0);
+        if (rc) return rc;
+        if (with_idx) HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (uint64_t)nb * n * 8, c->stream)); // query.h:937-938
+        hipLaunchKernelGGL(k_bounds_reset, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_upper, c->d_lower); // :941-942
+        Dev d = make_dev(c, nb, with_idx != 0);
+        hipLaunchKernelGGL(k_init_batch, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
+        active.assign((size_t)nb, 1);
+        for (int i = 0; i < nb; i++) // dangling source: query.h:951-955
+            if (c->h_row_ptr[sources[b0 + i] + 1] == c->h_row_ptr[sources[b0 + i]]) active[i] = 0;
+        std::vector<int32_t> nround((size_t)nb, 1);
+        hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
+                           (const uint8_t *)nullptr);
+        double delta = init_delta;
+        int round = 0;
+        while (delta >= min_delta) { // query.h:944
+            bool any = false;
+            for (int i = 0; i < nb; i++) any |= active[i] != 0;
+            if (!any) break;
+            round++;
+            double rmax = epsilon * sqrt(delta / 3 / m / L); // fora_setting with the round's delta, algo.h:455-463
+            rmax *= rmax_scale;
+            const double omega = (2 + epsilon) * L / delta / epsilon / epsilon;
+            for (int i = 0; i < nb; i++) if (active[i]) nround[i] = round;
+            HIPCHK(c, hipMemcpyAsync(c->d_active, active.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_above, 0, (size_t)nb * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_fail, 0, (size_t)nb * 4, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_round_walks, 0, (size_t)nb * 8, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_wit_count, 0, (size_t)c->B * 4 * CSTRIDE, c->stream));
+            rc = reset_binned_counters(c);
+            if (rc) return rc;
+            d = make_dev(c, nb, with_idx != 0, rmax, omega);
+            int h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, d, (const uint8_t *)c->d_active);
+            ev_end(c, h);
+            rc = run_push_levels(c, d); // algo.h:1020-1093
+            if (rc) return rc;
+            // compute_ppr_with_fwdidx_topk_with_bound, query.h:639-750, into ppr2
+            h = ev_begin(c, 4);
+            hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
+                               (const uint8_t *)c->d_active);
+            ev_end(c, h);
+            Dev dw = d;
+            dw.ppr = c->d_ppr2;
+            h = ev_begin(c, 2);
+            hipLaunchKernelGGL(k_walk_alloc<ALLOC_BOUND>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
+                               (const uint8_t *)c->d_active, c->d_cursor, c->d_round_walks);
+            ev_end(c, h);
+            launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, 0);
+            h = ev_begin(c, 4);
+            if (delta < threshold) // query.h:745-746
+                hipLaunchKernelGGL(k_bounds_update, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, (const uint64_t *)c->d_ppr,
+                                   (const uint8_t *)c->d_active, (const unsigned long long *)c->d_round_walks, L,
+                                   1.0 / c->n, sqrt(1.0 / c->n), c->d_upper, c->d_lower);
+            // if_stop, algo.h:1096-1166
+            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,
+                               (const uint8_t *)c->d_active, 2.0 * delta, c->d_above);
+            const bool bounds_on = !(delta >= threshold);
+            if (bounds_on) {
+                Dev dl = dw;
+                dl.ppr = (uint64_t *)c->d_lower; // non-negative f64: bit patterns order like the values
+                hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, dl, k, c->d_lb_ids, c->d_lb_sc, 1);
+                hipLaunchKernelGGL(k_bound_ratio, dim3(nb), dim3(SEL_THREADS), 0, c->stream, dw, k, (const int32_t *)c->d_lb_ids,
+                                   (const double *)c->d_lb_sc, (const uint8_t *)c->d_active, (const double *)c->d_upper,
+                                   1.0 + epsilon, c->d_filter, c->d_fail);
+                hipLaunchKernelGGL(k_bound_scan, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, k, (const double *)c->d_lb_sc,
+                                   (const uint8_t *)c->d_active, (const double *)c->d_upper, (const double *)c->d_lower, delta,
+                                   1.0 + epsilon, (1 + epsilon) / (1 - epsilon), c->d_filter, c->d_fail);
+            }
+            ev_end(c, h);
+            above.assign((size_t)nb, 0);
+            failv.assign((size_t)nb, 0);
+            HIPCHK(c, hipMemcpyAsync(above.data(), c->d_above, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(failv.data(), c->d_fail, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+            rc = check_dev_err(c);
+            if (rc) return rc;
+            for (int i = 0; i < nb; i++) {
+                if (!active[i]) continue;
+                const bool stop = above[i] >= (unsigned long long)k || (bounds_on && failv[i] == 0);
+                if (stop || delta <= min_delta) active[i] = 0; // query.h:962-964
+            }
+            if (delta <= min_delta) break;
+            delta = std::max(min_delta, delta / 2.0); // query.h:966
+        }
+        Dev ds = make_dev(c, nb, false);
+        ds.ppr = c->d_ppr2;
+        int h = ev_begin(c, 4);
+        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc, 0);
+        ev_end(c, h);
+        ev_end(c, hb);
+        HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(scores + (size_t)b0 * k, c->d_topk_sc, (size_t)nb * k * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("topk (bounds): ") + hipGetErrorString(e));
+        ev_collect(c);
+        HIPCHK(c, hipMemcpy(c->h_qs.data(), c->d_qs, (size_t)nb * sizeof(QState), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nb; i++) {
             c->timing.pops += c->h_qs[i].pops;
             c->timing.relax += c->h_qs[i].relax;
             c->timing.walks += c->h_qs[i].n_walks;
@@ -1153,7 +1332,7 @@ int fora_hip_power_iteration_batch(fora_ctx *c, const int32_t *sources, int nq, 
         if (rc) return rc;
         if (want_topk) {
             int h = ev_begin(c, 4);
-            hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, d, k, c->d_topk_ids, c->d_topk_sc);
+            hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, d, k, c->d_topk_ids, c->d_topk_sc, 0);
             ev_end(c, h);
             HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(scores + (size_t)b0 * k, c->d_topk_sc, (size_t)nb * k * 8, hipMemcpyDeviceToHost, c->stream));

@@ -813,13 +813,15 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
 //   ALLOC_QUERY: num_s_rw = ceil(r/rsum*N)  (query.h:270,282-287; --opt: query.h:349,363-364)
 //   ALLOC_TOPK : num_s_rw = ceil(r*omega), index consumed through a per-node cursor so walks
 //                are never reused across rounds (query.h:558-611; online: query.h:616-632)
-enum { ALLOC_QUERY = 0, ALLOC_TOPK = 1 };
+//   ALLOC_BOUND: top-k with bounds (query.h:639-741): no one-hop split; num_s_rw = ceil(r*omega) with the index
+//                (cursor as ALLOC_TOPK), ceil(r/rsum*N) without; the round's walk total goes to round_walks[q]
+enum { ALLOC_QUERY = 0, ALLOC_TOPK = 1, ALLOC_BOUND = 2 };
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const uint8_t *active,
-                                                      uint64_t *cursor) {
+                                                      uint64_t *cursor, unsigned long long *round_walks) {
     const int q = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    if (MODE == ALLOC_TOPK && !active[q]) return;
+    if (MODE != ALLOC_QUERY && !active[q]) return;
     QState *qs = &d.qs[q];
     const uint64_t rsum_fix = FIX_ONE - qs->reserved;
     if (rsum_fix == 0) return; // query.h:267-268 / :535-536
@@ -830,7 +832,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
         N = (uint64_t)(d.omega * check_rsum);         // query.h:270
         if (blockIdx.x == 0 && threadIdx.x == 0) qs->n_rw = N;
     }
-    const bool split = MODE == ALLOC_QUERY ? d.opt != 0 : with_idx != 0;
+    if (MODE == ALLOC_BOUND) N = (uint64_t)(d.omega * check_rsum); // query.h:645
+    const bool split = MODE == ALLOC_QUERY ? d.opt != 0 : MODE == ALLOC_TOPK ? with_idx != 0 : false;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
     uint64_t acc_walks = 0, acc_hit = 0;
@@ -845,8 +848,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                 d.ppr[slab + v] += keep;
                 r -= keep;
             }
-            if (MODE == ALLOC_QUERY) num = walk_count(fix2d(r), check_rsum, N);
-            else num = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618
+            if (MODE == ALLOC_QUERY || (MODE == ALLOC_BOUND && !with_idx)) num = walk_count(fix2d(r), check_rsum, N); // :727
+            else num = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618 / :659
             if (num) {
                 incr = r / num;
                 rem = r - incr * num;
@@ -854,7 +857,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                 if (with_idx) {
                     const uint64_t icnt = d.idx_cnt[v];
                     ipos = d.idx_off[v];
-                    if (MODE == ALLOC_TOPK) { // query.h:575-603
+                    if (MODE != ALLOC_QUERY) { // query.h:575-603 / :668-709
                         const uint64_t used = cursor[slab + v];
                         iav = icnt - used;
                         if (iav > num) iav = num;
@@ -899,6 +902,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
     if (lane == 0) {
         if (acc_walks) atomicAdd(&qs->n_walks, (unsigned long long)acc_walks);
         if (acc_hit) atomicAdd(&qs->n_hit, (unsigned long long)acc_hit);
+        if (MODE == ALLOC_BOUND && acc_walks) atomicAdd(&round_walks[q], (unsigned long long)acc_walks);
     }
 }
 
@@ -952,7 +956,9 @@ __global__ void __launch_bounds__(BLOCK) k_count_above(Dev d, const uint8_t *act
 // select of the k-th value (LDS histograms), ordered compaction, bitonic sort in LDS.
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAXK = 1024;
-__global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32_t *ids, double *scores) {
+// raw != 0: the slab holds non-negative f64 (lower bounds; their bit patterns order like the values) and the
+// scores are those doubles.
+__global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32_t *ids, double *scores, int raw) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_key[SEL_MAXK];
     __shared__ uint32_t s_id[SEL_MAXK];
@@ -1065,7 +1071,104 @@ __global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32
     for (uint32_t i = tid; i < (uint32_t)k; i += SEL_THREADS) {
         const bool ok = i < have;
         ids[(uint64_t)q * k + i] = ok ? (int32_t)s_id[i] : 0;
-        scores[(uint64_t)q * k + i] = ok ? fix2d(s_key[i]) : 0.0;
+        scores[(uint64_t)q * k + i] = ok ? (raw ? __longlong_as_double((long long)s_key[i]) : fix2d(s_key[i])) : 0.0;
+    }
+}
+
+// ---- top-k with bounds (get_topk without --opt): set_ppr_bounds (algo.h:1178-1261) and if_stop (algo.h:1096-1166).
+// Per node only +, *, / and sqrt of f64 in the reference's operand order (L = log(2/pfail) comes from the host), so
+// the bounds equal oracle/fora_twin.c's bit for bit.  upper / lower: [slot][n] f64 (upper_bounds / lower_bounds,
+// query.h:1350-1353: every key present, reset to 1 / 0 per query, :941-942).
+__device__ __forceinline__ double bound_lambda(double rsum, double L, double upper_bound, double total) { // algo.h:1169-1174
+    return 1.0 / 3 * L * rsum / total + sqrt(4.0 / 9.0 * L * L * rsum * rsum + 8 * total * L * rsum * upper_bound) / 2.0 / total;
+}
+// grid = (chunks, nq).  ppr: refined estimate of the round, reserve: the push's reserve slab.
+__global__ void __launch_bounds__(BLOCK) k_bounds_update(Dev d, const uint64_t *reserve_slab, const uint8_t *active,
+                                                         const unsigned long long *round_walks, double L,
+                                                         double min_ppr, double sqrt_min_ppr, double *upper, double *lower) {
+    const int q = blockIdx.y;
+    if (!active[q]) return;
+    const uint64_t rsum_fix = FIX_ONE - d.qs[q].reserved;
+    if (rsum_fix == 0) return; // query.h:642-643: no walks, no bound update
+    const double rsum = fix2d(rsum_fix);
+    const double total = (double)round_walks[q];
+    const double epsilon_v_div = sqrt(2.67 * rsum * L / total);
+    const double default_epsilon_v = epsilon_v_div / sqrt_min_ppr;
+    const uint64_t slab = (uint64_t)q * d.n;
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t pf = d.ppr[slab + v];
+        if (!pf) continue; // algo.h:1200-1201
+        const double p = fix2d(pf);
+        double reserve = fix2d(reserve_slab[slab + v]);
+        const double up0 = upper[slab + v], lo0 = lower[slab + v];
+        double epsilon_a;
+        if (up0 > reserve) epsilon_a = bound_lambda(rsum, L, up0 - reserve, total); // :1211-1215
+        else epsilon_a = bound_lambda(rsum, L, 1 - reserve, total);
+        const double ub_eps_a = p + epsilon_a;
+        double lb_eps_a = p - epsilon_a;
+        if (!(lb_eps_a > 0)) lb_eps_a = 0;
+        double epsilon_v = default_epsilon_v;
+        if (reserve > 0 && reserve > min_ppr) { // :1230-1233
+            reserve = reserve > lo0 ? reserve : lo0;
+            epsilon_v = epsilon_v_div / sqrt(reserve);
+        } else if (lo0 > 0) {                   // :1235-1236
+            epsilon_v = epsilon_v_div / sqrt(lo0);
+        }
+        double ub_eps_v = 1.0, lb_eps_v = 0.0;
+        if (1.0 - epsilon_v > 0) {
+            ub_eps_v = p / (1.0 - epsilon_v);
+            lb_eps_v = p / (1.0 + epsilon_v);
+        }
+        double up_bound = ub_eps_a < ub_eps_v ? ub_eps_a : ub_eps_v;
+        if (!(up_bound < 1.0)) up_bound = 1.0;
+        double low_bound = lb_eps_a > lb_eps_v ? lb_eps_a : lb_eps_v;
+        if (!(low_bound > reserve)) low_bound = reserve;
+        if (up_bound > 0) upper[slab + v] = up_bound;
+        if (low_bound >= 0) lower[slab + v] = low_bound;
+    }
+}
+// if_stop, part 1 (algo.h:1122-1136): the k nodes with the largest lower bounds (selected by k_topk_select in raw
+// mode) are marked and must satisfy upper/lower <= 1 + eps.  grid = nq, SEL_THREADS threads.
+__global__ void __launch_bounds__(SEL_THREADS) k_bound_ratio(Dev d, int k, const int32_t *ids, const double *lbs,
+                                                             const uint8_t *active, const double *upper, double error,
+                                                             uint8_t *filter, uint32_t *fail) {
+    const int q = blockIdx.x;
+    if (!active[q]) return;
+    const uint64_t slab = (uint64_t)q * d.n;
+    bool bad = false;
+    for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+        const double lb = lbs[(uint64_t)q * k + i];
+        if (!(lb > 0)) { bad = true; continue; } // fewer than k positive lower bounds: upper/0 = inf > error
+        const uint32_t id = (uint32_t)ids[(uint64_t)q * k + i];
+        filter[slab + id] = 1;
+        if (upper[slab + id] / lb > error) bad = true;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&fail[q], 1u);
+}
+// part 2 (algo.h:1144-1163): k-th lower bound above delta, and no unmarked node with ppr > 0 whose upper bound
+// reaches it unless its own bounds are still loose.  Clears the marks.  grid = (chunks, nq).
+__global__ void __launch_bounds__(BLOCK) k_bound_scan(Dev d, int k, const double *lbs, const uint8_t *active,
+                                                      const double *upper, const double *lower, double delta,
+                                                      double error, double loose, uint8_t *filter, uint32_t *fail) {
+    const int q = blockIdx.y;
+    if (!active[q]) return;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const double low_k = lbs[(uint64_t)q * k + (k - 1)];
+    bool bad = !(low_k > delta); // :1145-1147
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK) {
+        if (filter[slab + v]) { filter[slab + v] = 0; continue; }
+        if (!d.ppr[slab + v]) continue;
+        const double up = upper[slab + v];
+        if (up > low_k * error && !(up > loose * lower[slab + v])) bad = true;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&fail[q], 2u);
+}
+// upper := 1, lower := 0 for the batch (query.h:941-942)
+__global__ void __launch_bounds__(BLOCK) k_bounds_reset(int32_t n, double *upper, double *lower) {
+    const uint64_t slab = (uint64_t)blockIdx.y * n;
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)n; v += (uint64_t)gridDim.x * BLOCK) {
+        upper[slab + v] = 1.0;
+        lower[slab + v] = 0.0;
     }
 }
 

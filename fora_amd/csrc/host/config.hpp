@@ -40,6 +40,7 @@ struct Config { // config.h:86-160
     unsigned int query_size = 1000; // config.h:113
     double pfail = 0, dbar = 0, epsilon = 0, delta = 0;
     unsigned int k = 500;          // config.h:122
+    double ppr_decay_alpha = 0.77; // config.h:123
     double rw_cost_ratio = 8.0;    // config.h:125
     double rmax_scale = 1;         // config.h:127
     std::string algo;

@@ -293,7 +293,7 @@ static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
     return 0;
 }
 
-static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with --opt
+static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch
     std::vector<int32_t> queries;
     if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); }
     info("queries.size()", queries.size());
@@ -301,10 +301,6 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
     if (!(config.k < (unsigned)graph.n - 1) || !(config.k > 1)) { cerr << "k out of range" << endl; return 1; } // :1317-1318
     info("config.k", config.k);
     split_line();
-    if (!config.opt) { // fora_query_topk_with_bound (query.h:909-969) is SURVEY.md 8f rank 2
-        cerr << "topk without --opt (bounds variant) is not part of this build; pass --opt" << endl;
-        return 1;
-    }
     IndexData index;
     if (config.with_rw_idx) {
         string err;
@@ -322,9 +318,13 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch with
             const size_t nl = s.sources.size();
             std::vector<int32_t> lid(nl * k), lr(nl);
             std::vector<double> lsc(nl * k);
-            if (fora_hip_topk_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon, config.rmax_scale, config.with_rw_idx,
-                                    lid.data(), lsc.data(), lr.data()))
-                return 1;
+            // get_topk, query.h:1150-1153: --opt -> fora_query_topk_new, else fora_query_topk_with_bound
+            const int rc = config.opt ? fora_hip_topk_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon, config.rmax_scale,
+                                                            config.with_rw_idx, lid.data(), lsc.data(), lr.data())
+                                      : fora_hip_topk_bound_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon,
+                                                                  config.rmax_scale, config.ppr_decay_alpha, config.with_rw_idx,
+                                                                  lid.data(), lsc.data(), lr.data());
+            if (rc) return 1;
             for (size_t i = 0; i < nl; i++) { // the "gather": top-k lists back in query order
                 std::copy(lid.begin() + (long)(i * k), lid.begin() + (long)((i + 1) * k), ids.begin() + (long)(s.pos[i] * k));
                 std::copy(lsc.begin() + (long)(i * k), lsc.begin() + (long)((i + 1) * k), scores.begin() + (long)(s.pos[i] * k));

@@ -126,6 +126,13 @@ int fora_hip_topk_batch(fora_ctx *ctx, const int32_t *sources, int nq, int k, do
                         double rmax_scale, int with_idx, int32_t *ids, double *scores,
                         int32_t *rounds /*nq or NULL*/);
 
+/* ---- top-k with bounds: get_topk without --opt -> fora_query_topk_with_bound + topk_ppr (query.h:1139-1156,
+ * 909-969, 639-750; set_ppr_bounds algo.h:1178-1261; if_stop algo.h:1096-1166).  ppr_decay_alpha: config.h:123
+ * (0.77).  With with_idx the index must have been built without --opt.  Outputs as fora_hip_topk_batch. */
+int fora_hip_topk_bound_batch(fora_ctx *ctx, const int32_t *sources, int nq, int k, double epsilon,
+                              double rmax_scale, double ppr_decay_alpha, int with_idx, int32_t *ids,
+                              double *scores, int32_t *rounds /*nq or NULL*/);
+
 /* ---- exact SSPPR: replaces fwd_power_iteration / multi_power_iter under gen_exact_topk
  * (query.h:1192-1238, 1240-1307): max_iter Jacobi iterations (config.max_iter_num, config.h:115 = 100) of
  * "keep alpha of every positive residual, push the rest along the out-edges, dangling mass back to the

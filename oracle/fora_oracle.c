@@ -574,6 +574,205 @@ int orc_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *
     return 0;
 }
 
+/* ---------------------------------------------------- top-k with bounds (non --opt) */
+/* algo.h:1169-1174 calculate_lambda, operand order kept. */
+double orc_calculate_lambda(double rsum, double pfail, double upper_bound, long total_rw_num) {
+    return 1.0 / 3 * log(2 / pfail) * rsum / total_rw_num +
+           sqrt(4.0 / 9.0 * log(2.0 / pfail) * log(2.0 / pfail) * rsum * rsum +
+                8 * total_rw_num * log(2.0 / pfail) * rsum * upper_bound) /
+               2.0 / total_rw_num;
+}
+
+/* algo.h:1178-1261 set_ppr_bounds.  upper / lower: dense n (init_keys + reset_one / reset_zero,
+ * query.h:1350-1353, :939-940), so exist() is always true for them. */
+static void set_ppr_bounds(int32_t n, double rsum, long total_rw_num, double pfail, const smap *reserve_m,
+                           const smap *ppr, double *upper, double *lower) {
+    const double min_ppr = 1.0 / n;
+    const double sqrt_min_ppr = sqrt(1.0 / n);
+    double epsilon_v_div = sqrt(2.67 * rsum * log(2.0 / pfail) / total_rw_num);
+    double default_epsilon_v = epsilon_v_div / sqrt_min_ppr;
+    for (int64_t i = 0; i < ppr->n_occur; i++) {
+        int32_t nodeid = ppr->occur[i];
+        if (ppr->val[nodeid] <= 0) continue;
+        double reserve = 0.0;
+        if (reserve_m->has[nodeid]) reserve = reserve_m->val[nodeid];
+        double epsilon_a;
+        if (upper[nodeid] > reserve) /* :1211-1215 (upper_bounds.exist is always true) */
+            epsilon_a = orc_calculate_lambda(rsum, pfail, upper[nodeid] - reserve, total_rw_num);
+        else
+            epsilon_a = orc_calculate_lambda(rsum, pfail, 1 - reserve, total_rw_num);
+        double ub_eps_a = ppr->val[nodeid] + epsilon_a;
+        double lb_eps_a = ppr->val[nodeid] - epsilon_a;
+        if (!(lb_eps_a > 0)) lb_eps_a = 0;
+        double epsilon_v = default_epsilon_v;
+        if (reserve_m->has[nodeid] && reserve_m->val[nodeid] > min_ppr) { /* :1230-1233 */
+            reserve = reserve > lower[nodeid] ? reserve : lower[nodeid];
+            epsilon_v = epsilon_v_div / sqrt(reserve);
+        } else if (lower[nodeid] > 0) { /* :1235-1236 */
+            epsilon_v = epsilon_v_div / sqrt(lower[nodeid]);
+        }
+        double ub_eps_v = 1.0, lb_eps_v = 0.0;
+        if (1.0 - epsilon_v > 0) {
+            ub_eps_v = ppr->val[nodeid] / (1.0 - epsilon_v);
+            lb_eps_v = ppr->val[nodeid] / (1.0 + epsilon_v);
+        }
+        double up_bound = ub_eps_a < ub_eps_v ? ub_eps_a : ub_eps_v;
+        if (!(up_bound < 1.0)) up_bound = 1.0;
+        double low_bound = lb_eps_a > lb_eps_v ? lb_eps_a : lb_eps_v;
+        if (!(low_bound > reserve)) low_bound = reserve;
+        if (up_bound > 0) upper[nodeid] = up_bound;
+        if (low_bound >= 0) lower[nodeid] = low_bound;
+    }
+}
+
+typedef struct { int32_t id; double sc; } idlb;
+static int cmp_idlb(const void *a, const void *b) {
+    const idlb *x = (const idlb *)a, *y = (const idlb *)b;
+    if (x->sc != y->sc) return (x->sc < y->sc) - (x->sc > y->sc);
+    return (x->id > y->id) - (x->id < y->id); /* tie order unspecified in algo.h:1123; id asc here */
+}
+
+/* algo.h:1096-1166 if_stop. */
+static int if_stop_bound(int32_t n, int32_t k, double delta, double threshold, double epsilon, const smap *ppr,
+                         const double *upper, const double *lower, double *tmp, idlb *tb, unsigned char *filter) {
+    double kth = 0; /* kth_ppr, algo.h:578-590 (0 when fewer than k entries: the reference reads out of range) */
+    if (ppr->n_occur >= k) {
+        for (int64_t i = 0; i < ppr->n_occur; i++) tmp[i] = ppr->val[ppr->occur[i]];
+        qsort(tmp, (size_t)ppr->n_occur, sizeof(double), cmp_desc_d);
+        kth = tmp[k - 1];
+    }
+    if (kth >= 2.0 * delta) return 1;
+    if (delta >= threshold) return 0;
+    const double error = 1.0 + epsilon, error_2 = 1.0 + epsilon;
+    for (int32_t v = 0; v < n; v++) { tb[v].id = v; tb[v].sc = lower[v]; } /* lower_bounds.occur = 0..n-1 */
+    qsort(tb, (size_t)n, sizeof(idlb), cmp_idlb);                          /* partial_sort_copy :1122 */
+    memset(filter, 0, (size_t)n);
+    for (int32_t i = 0; i < k; i++) { /* :1128-1136 */
+        filter[tb[i].id] = 1;
+        double ratio = upper[tb[i].id] / lower[tb[i].id];
+        if (ratio > error_2) return 0;
+    }
+    double low_bound_k = tb[k - 1].sc;
+    if (low_bound_k <= delta) return 0; /* :1145-1147 */
+    for (int32_t v = 0; v < n; v++) {    /* :1148-1163; ppr[v] is nil (-9) when absent */
+        if (filter[v] || !ppr->has[v] || ppr->val[v] <= 0) continue;
+        double upper_temp = upper[v], lower_temp = lower[v];
+        if (upper_temp > low_bound_k * error) {
+            if (upper_temp > (1 + epsilon) / (1 - epsilon) * lower_temp) continue;
+            else return 0;
+        }
+    }
+    return 1;
+}
+
+/* query.h:909-969 fora_query_topk_with_bound + compute_ppr_with_fwdidx_topk_with_bound (query.h:639-750)
+ * + topk_ppr (algo.h:592-610).  zero_ppr_upper_bound (query.h:935, :748) only ever feeds itself and is not
+ * kept.  Walk numbering: walk j of node `source` in round `nround` (index entries first, then online). */
+int orc_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                         int32_t k, double epsilon, double alpha, double rmax_scale, double ppr_decay_alpha,
+                         uint64_t seed, const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                         int32_t *ids, double *scores, int32_t *rounds, double *ppr_out) {
+    const double min_delta = 1.0 / n;                                                    /* :911 */
+    const double init_delta = 1.0 / 4;                                                   /* :912 */
+    const double threshold = (1.0 - ppr_decay_alpha) / pow(500, ppr_decay_alpha) / pow(n, 1 - ppr_decay_alpha); /* :913 */
+    const double new_pfail = 1.0 / n / n / log(n);                                       /* :915 */
+    double pfail = new_pfail, delta = init_delta;                                        /* :917-918 */
+    const double lowest_delta_rmax = epsilon * sqrt(min_delta / 3 / m / log(2 / new_pfail)); /* :920 */
+    double rsum = 1.0;
+    smap reserve, residue, ppr;
+    smap_init(&reserve, n); smap_init(&residue, n); smap_init(&ppr, n);
+    ivec forward_from = {0, 0, 0};
+    ivec_push(&forward_from, s);
+    smap_insert(&residue, s, rsum);
+    uint64_t *rw_counter = rw_idx ? (uint64_t *)calloc((size_t)n, sizeof(uint64_t)) : NULL; /* :937-938 */
+    double *upper = (double *)malloc(sizeof(double) * (size_t)n), *lower = (double *)calloc((size_t)n, sizeof(double));
+    for (int32_t v = 0; v < n; v++) upper[v] = 1.0; /* :941-942 */
+    unsigned char *f1 = (unsigned char *)malloc((size_t)n), *f2 = (unsigned char *)malloc((size_t)n);
+    unsigned char *filter = (unsigned char *)malloc((size_t)n);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+    idlb *tb = (idlb *)malloc(sizeof(idlb) * (size_t)n);
+    int32_t nround = 0;
+
+    while (delta >= min_delta) { /* :944 */
+        double rmax = epsilon * sqrt(delta / 3 / m / log(2 / pfail)); /* fora_setting, algo.h:455-463 */
+        rmax *= rmax_scale;
+        double omega = (2 + epsilon) * log(2 / pfail) / delta / epsilon / epsilon;
+        nround++;
+        if (row_ptr[s + 1] == row_ptr[s]) { /* :951-955 */
+            rsum = 0.0;
+            smap_insert(&reserve, s, 1);
+            smap_clean(&ppr);
+            smap_insert(&ppr, s, 1);
+            break;
+        }
+        push_fifo_topk(n, row_ptr, col, s, &rsum, rmax, lowest_delta_rmax, alpha, &reserve, &residue,
+                       &forward_from, f1, f2); /* :957 */
+        /* compute_ppr_with_fwdidx_topk_with_bound */
+        smap_clean(&ppr);
+        for (int64_t i = 0; i < reserve.n_occur; i++) {
+            int32_t v = reserve.occur[i];
+            if (reserve.val[v]) smap_insert(&ppr, v, reserve.val[v]);
+        }
+        if (rsum != 0.0) { /* :642-643 */
+            long num_random_walk = (long)(omega * rsum); /* :645 */
+            long real_num_rand_walk = 0;
+            if (rw_idx) { /* :652-721 */
+                qsort(residue.occur, (size_t)residue.n_occur, sizeof(int32_t), cmp_i32);
+                for (int64_t i = 0; i < residue.n_occur; i++) {
+                    int32_t source = residue.occur[i];
+                    double residual = residue.val[source];
+                    long num_s_rw = (long)ceil(residual * omega);                         /* :659 */
+                    double a_s = residual / rsum * num_random_walk / num_s_rw;             /* :660 */
+                    double ppr_incre = a_s * rsum / num_random_walk;                       /* :662 */
+                    real_num_rand_walk += num_s_rw;
+                    uint64_t used = rw_counter[source];
+                    long remaining = (long)(cnt[source] - used);
+                    long from_idx = num_s_rw <= remaining ? num_s_rw : remaining;
+                    for (long kk = 0; kk < from_idx; kk++) smap_add(&ppr, rw_idx[off[source] + used + (uint64_t)kk], ppr_incre);
+                    rw_counter[source] = used + (uint64_t)from_idx;
+                    for (long j = from_idx; j < num_s_rw; j++) { /* :711-718 */
+                        int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, (uint32_t)nround, source,
+                                               (uint64_t)j, alpha, 0, NULL);
+                        smap_add(&ppr, des, ppr_incre);
+                    }
+                }
+            } else { /* :723-741 */
+                for (int64_t i = 0; i < residue.n_occur; i++) {
+                    int32_t source = residue.occur[i];
+                    double residual = residue.val[source];
+                    long num_s_rw = (long)ceil(residual / rsum * num_random_walk);         /* :727 */
+                    double a_s = residual / rsum * num_random_walk / num_s_rw;
+                    real_num_rand_walk += num_s_rw;
+                    double ppr_incre = a_s * rsum / num_random_walk;
+                    for (long j = 0; j < num_s_rw; j++) {
+                        int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, (uint32_t)nround, source,
+                                               (uint64_t)j, alpha, 0, NULL);
+                        smap_add(&ppr, des, ppr_incre);
+                    }
+                }
+            }
+            if (delta < threshold) /* :745-746 */
+                set_ppr_bounds(n, rsum, real_num_rand_walk, pfail, &reserve, &ppr, upper, lower);
+        }
+        if (if_stop_bound(n, k, delta, threshold, epsilon, &ppr, upper, lower, tmp, tb, filter) || delta <= min_delta)
+            break; /* :962-964 */
+        delta = delta / 2.0 > min_delta ? delta / 2.0 : min_delta; /* :966 */
+    }
+    idsc *all = (idsc *)malloc(sizeof(idsc) * (size_t)(ppr.n_occur + 1));
+    for (int64_t i = 0; i < ppr.n_occur; i++) { all[i].id = ppr.occur[i]; all[i].sc = ppr.val[ppr.occur[i]]; }
+    qsort(all, (size_t)ppr.n_occur, sizeof(idsc), cmp_idsc);
+    for (int32_t i = 0; i < k; i++) {
+        if (i < ppr.n_occur) { ids[i] = all[i].id; scores[i] = all[i].sc; }
+        else { ids[i] = 0; scores[i] = 0.0; }
+    }
+    if (rounds) *rounds = nround;
+    if (ppr_out) memcpy(ppr_out, ppr.val, sizeof(double) * (size_t)n);
+    free(all); free(tmp); free(tb); free(f1); free(f2); free(filter); free(rw_counter); free(forward_from.a);
+    free(upper); free(lower);
+    smap_free(&reserve); smap_free(&residue); smap_free(&ppr);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- exact PPR */
 /* query.h:1192-1224 fwd_power_iteration, dense: alpha*r kept, (1-alpha)*r spread over
  * out-neighbours, dangling mass returned to the start node (:1210-1212). */

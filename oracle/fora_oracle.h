@@ -111,6 +111,13 @@ int orc_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *
                    const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
                    int32_t *ids, double *scores, int32_t *rounds, double *ppr_out);
 
+/* ---- top-k with bounds (get_topk without --opt): query.h:909-969, :639-750, algo.h:1096-1261 ---- */
+double orc_calculate_lambda(double rsum, double pfail, double upper_bound, long total_rw_num);
+int orc_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                         int32_t k, double epsilon, double alpha, double rmax_scale, double ppr_decay_alpha,
+                         uint64_t seed, const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                         int32_t *ids, double *scores, int32_t *rounds, double *ppr_out);
+
 /* ---- exact PPR: query.h:1192-1224 (dense restatement, `iters` rounds) ---- */
 void orc_power_iteration(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s,
                          double alpha, int iters, double *ppr);
@@ -145,6 +152,14 @@ int orc_twin_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int3
                         int32_t k, double epsilon, double alpha, double rmax_scale, uint64_t seed,
                         const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
                         int32_t *ids, double *scores, int32_t *rounds, uint64_t *ppr_out);
+/* top-k with bounds in the twin's schedule; upper_out / lower_out (n doubles, optional): final bounds */
+int orc_twin_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                              int32_t k, double epsilon, double alpha, double rmax_scale, double ppr_decay_alpha,
+                              uint64_t seed, const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                              int32_t *ids, double *scores, int32_t *rounds, uint64_t *ppr_out,
+                              double *upper_out, double *lower_out);
+void orc_twin_bounds_node(double p, double reserve, double rsum, double L, double total, double min_ppr,
+                          double sqrt_min_ppr, double *upper, double *lower);
 void orc_fix_to_double(const uint64_t *in, int64_t n, double *out);
 
 #ifdef __cplusplus

@@ -331,3 +331,177 @@ int orc_twin_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int3
     free(all); free(residue); free(reserve); free(ppr); free(cursor); free(frontier); free(next); free(inc);
     return 0;
 }
+
+/* ---- top-k with bounds (get_topk without --opt, query.h:909-969) in the twin's schedule ---------------------
+ * Push / walks as in orc_twin_topk_query; the bounds (algo.h:1178-1261) and the stop rule (algo.h:1096-1166) are
+ * f64 expressions of fix2d(ppr), fix2d(reserve) evaluated in the reference's operand order with L = log(2/pfail)
+ * computed once -- +,*,/ and sqrt only per node, so the GPU reproduces them bit for bit. */
+static inline double twin_lambda(double rsum, double L, double upper_bound, double total) {
+    /* algo.h:1169-1174; total = (double)total_rw_num, 8*total exact below 2^50 */
+    return 1.0 / 3 * L * rsum / total + sqrt(4.0 / 9.0 * L * L * rsum * rsum + 8 * total * L * rsum * upper_bound) / 2.0 / total;
+}
+void orc_twin_bounds_node(double p, double reserve, double rsum, double L, double total, double min_ppr,
+                          double sqrt_min_ppr, double *upper, double *lower) {
+    const double epsilon_v_div = sqrt(2.67 * rsum * L / total);
+    const double default_epsilon_v = epsilon_v_div / sqrt_min_ppr;
+    const double up0 = *upper, lo0 = *lower;
+    double epsilon_a;
+    if (up0 > reserve) epsilon_a = twin_lambda(rsum, L, up0 - reserve, total);
+    else epsilon_a = twin_lambda(rsum, L, 1 - reserve, total);
+    const double ub_eps_a = p + epsilon_a;
+    double lb_eps_a = p - epsilon_a;
+    if (!(lb_eps_a > 0)) lb_eps_a = 0;
+    double epsilon_v = default_epsilon_v;
+    if (reserve > 0 && reserve > min_ppr) {
+        reserve = reserve > lo0 ? reserve : lo0;
+        epsilon_v = epsilon_v_div / sqrt(reserve);
+    } else if (lo0 > 0) {
+        epsilon_v = epsilon_v_div / sqrt(lo0);
+    }
+    double ub_eps_v = 1.0, lb_eps_v = 0.0;
+    if (1.0 - epsilon_v > 0) {
+        ub_eps_v = p / (1.0 - epsilon_v);
+        lb_eps_v = p / (1.0 + epsilon_v);
+    }
+    double up_bound = ub_eps_a < ub_eps_v ? ub_eps_a : ub_eps_v;
+    if (!(up_bound < 1.0)) up_bound = 1.0;
+    double low_bound = lb_eps_a > lb_eps_v ? lb_eps_a : lb_eps_v;
+    if (!(low_bound > reserve)) low_bound = reserve;
+    if (up_bound > 0) *upper = up_bound;
+    if (low_bound >= 0) *lower = low_bound;
+}
+
+typedef struct { int32_t id; double sc; } idlbt;
+static int cmp_idlbt(const void *a, const void *b) {
+    const idlbt *x = (const idlbt *)a, *y = (const idlbt *)b;
+    if (x->sc != y->sc) return (x->sc < y->sc) - (x->sc > y->sc);
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+int orc_twin_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,
+                              int32_t k, double epsilon, double alpha, double rmax_scale, double ppr_decay_alpha,
+                              uint64_t seed, const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
+                              int32_t *ids, double *scores, int32_t *rounds, uint64_t *ppr_out,
+                              double *upper_out, double *lower_out) {
+    const double min_delta = 1.0 / n;
+    const double init_delta = 1.0 / 4;
+    const double threshold = (1.0 - ppr_decay_alpha) / pow(500, ppr_decay_alpha) / pow(n, 1 - ppr_decay_alpha);
+    const double pfail = 1.0 / n / n / log(n);
+    const double L = log(2 / pfail);
+    const double min_ppr = 1.0 / n, sqrt_min_ppr = sqrt(1.0 / n);
+    double delta = init_delta;
+    uint64_t afix = orc_twin_alpha_fix(alpha);
+    uint64_t *residue = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *reserve = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *ppr = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    uint64_t *cursor = rw_idx ? (uint64_t *)calloc((size_t)n, sizeof(uint64_t)) : NULL;
+    double *upper = (double *)malloc(sizeof(double) * (size_t)n), *lower = (double *)calloc((size_t)n, sizeof(double));
+    for (int32_t v = 0; v < n; v++) upper[v] = 1.0;
+    int32_t *frontier = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int32_t *next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    idlbt *tb = (idlbt *)malloc(sizeof(idlbt) * (size_t)n);
+    unsigned char *filter = (unsigned char *)malloc((size_t)n);
+    int32_t nround = 0;
+    residue[s] = ORC_FIX_ONE;
+
+    while (delta >= min_delta) {
+        double rmax = epsilon * sqrt(delta / 3 / m / L); /* fora_setting with the round's delta, algo.h:455-463 */
+        rmax *= rmax_scale;
+        double omega = (2 + epsilon) * L / delta / epsilon / epsilon;
+        nround++;
+        if (row_ptr[s + 1] == row_ptr[s]) { /* query.h:951-955 */
+            residue[s] = 0;
+            reserve[s] = ORC_FIX_ONE;
+            memcpy(ppr, reserve, sizeof(uint64_t) * (size_t)n);
+            break;
+        }
+        uint64_t t1 = orc_twin_rmax_fix(rmax);
+        int64_t fn = 0;
+        for (int32_t v = 0; v < n; v++)
+            if (residue[v] >= node_thr(t1, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
+        orc_twin_push_stats ps = {0, 0, 0, 0};
+        twin_levels(row_ptr, col, s, t1, afix, residue, reserve, frontier, fn, next, inc, &ps, NULL, 0, 0);
+        uint64_t reserved = 0;
+        for (int32_t v = 0; v < n; v++) reserved += reserve[v];
+        uint64_t rsum_fix = ORC_FIX_ONE - reserved;
+        memcpy(ppr, reserve, sizeof(uint64_t) * (size_t)n);
+        if (rsum_fix != 0) {
+            double check_rsum = fix2d(rsum_fix);
+            unsigned long long N = (unsigned long long)(omega * check_rsum); /* query.h:645 */
+            uint64_t total = 0;
+            for (int32_t v = 0; v < n; v++) {
+                uint64_t r = residue[v];
+                if (!r) continue;
+                uint64_t num = rw_idx ? (uint64_t)ceil(fix2d(r) * omega)                      /* query.h:659 */
+                                      : (uint64_t)ceil(fix2d(r) / check_rsum * (double)N);     /* query.h:727 */
+                if (!num) continue;
+                total += num;
+                uint64_t incr = r / num, rem = r - incr * num;
+                uint64_t from_idx = 0;
+                if (rw_idx) {
+                    uint64_t used = cursor[v], remaining = cnt[v] - used;
+                    from_idx = num <= remaining ? num : remaining;
+                    for (uint64_t j = 0; j < from_idx; j++) ppr[rw_idx[off[v] + used + j]] += incr + (j < rem);
+                    cursor[v] = used + from_idx;
+                }
+                for (uint64_t j = from_idx; j < num; j++) {
+                    int32_t des = orc_walk(n, row_ptr, col, seed, (uint32_t)s, (uint32_t)nround, v, j, alpha, 0, NULL);
+                    ppr[des] += incr + (j < rem);
+                }
+            }
+            if (delta < threshold) /* query.h:745-746 */
+                for (int32_t v = 0; v < n; v++)
+                    if (ppr[v])
+                        orc_twin_bounds_node(fix2d(ppr[v]), fix2d(reserve[v]), check_rsum, L, (double)total, min_ppr,
+                                             sqrt_min_ppr, &upper[v], &lower[v]);
+        }
+        /* if_stop, algo.h:1096-1166 */
+        int stop = 0;
+        {
+            int64_t above = 0;
+            const double T = 2.0 * delta;
+            for (int32_t v = 0; v < n; v++) above += fix2d(ppr[v]) >= T;
+            if (above >= k) stop = 1;
+            else if (!(delta >= threshold)) {
+                for (int32_t v = 0; v < n; v++) { tb[v].id = v; tb[v].sc = lower[v]; }
+                qsort(tb, (size_t)n, sizeof(idlbt), cmp_idlbt);
+                memset(filter, 0, (size_t)n);
+                int ok = 1;
+                const double error = 1.0 + epsilon;
+                for (int32_t i = 0; i < k; i++) {
+                    /* zero lower bounds sort last among equals by id; the device select pads them: either way
+                     * the ratio is +inf and the test fails */
+                    filter[tb[i].id] = 1;
+                    if (upper[tb[i].id] / lower[tb[i].id] > error) ok = 0;
+                }
+                const double low_bound_k = tb[k - 1].sc;
+                if (ok && low_bound_k <= delta) ok = 0;
+                if (ok)
+                    for (int32_t v = 0; v < n; v++) {
+                        if (filter[v] || !ppr[v]) continue;
+                        if (upper[v] > low_bound_k * error && !(upper[v] > (1 + epsilon) / (1 - epsilon) * lower[v])) { ok = 0; break; }
+                    }
+                stop = ok;
+            }
+        }
+        if (stop || delta <= min_delta) break;
+        delta = delta / 2.0 > min_delta ? delta / 2.0 : min_delta;
+    }
+    idfix *all = (idfix *)malloc(sizeof(idfix) * ((size_t)n + 1));
+    int64_t na = 0;
+    for (int32_t v = 0; v < n; v++)
+        if (ppr[v]) { all[na].id = v; all[na].sc = ppr[v]; na++; }
+    qsort(all, (size_t)na, sizeof(idfix), cmp_idfix);
+    for (int32_t i = 0; i < k; i++) {
+        if (i < na) { ids[i] = all[i].id; scores[i] = fix2d(all[i].sc); }
+        else { ids[i] = 0; scores[i] = 0.0; }
+    }
+    if (rounds) *rounds = nround;
+    if (ppr_out) memcpy(ppr_out, ppr, sizeof(uint64_t) * (size_t)n);
+    if (upper_out) memcpy(upper_out, upper, sizeof(double) * (size_t)n);
+    if (lower_out) memcpy(lower_out, lower, sizeof(double) * (size_t)n);
+    free(all); free(residue); free(reserve); free(ppr); free(cursor); free(frontier); free(next); free(inc);
+    free(upper); free(lower); free(tb); free(filter);
+    return 0;
+}

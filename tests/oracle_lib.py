@@ -288,3 +288,38 @@ def twin_topk_query(g, s, k, epsilon, alpha=0.2, rmax_scale=1.0, seed=0, index=N
                               C.c_int32(k), _d(epsilon), _d(alpha), _d(rmax_scale), C.c_uint64(seed), a, b, c,
                               _p(ids), _p(sc), C.byref(rounds), _p(ppr))
     return ids, sc, rounds.value, ppr
+
+
+def topk_bound_query(g, s, k, epsilon, alpha=0.2, rmax_scale=1.0, ppr_decay_alpha=0.77, seed=0, index=None,
+                     want_ppr=False):
+    """get_topk without --opt (fora_query_topk_with_bound, query.h:909-969), reference arithmetic."""
+    ids = np.zeros(k, dtype=np.int32)
+    sc = np.zeros(k, dtype=np.float64)
+    rounds = C.c_int32(0)
+    ppr = np.zeros(g.n, dtype=np.float64) if want_ppr else None
+    a, b, c = _idx_args(index)
+    lib().orc_topk_bound_query(C.c_int32(g.n), C.c_int64(g.m), _p(g.row_ptr), _p(g.col), C.c_int32(s), C.c_int32(k),
+                               _d(epsilon), _d(alpha), _d(rmax_scale), _d(ppr_decay_alpha), C.c_uint64(seed), a, b, c,
+                               _p(ids), _p(sc), C.byref(rounds), _p(ppr))
+    return ids, sc, rounds.value, ppr
+
+
+def twin_topk_bound_query(g, s, k, epsilon, alpha=0.2, rmax_scale=1.0, ppr_decay_alpha=0.77, seed=0, index=None,
+                          want_ppr=False, want_bounds=False):
+    ids = np.zeros(k, dtype=np.int32)
+    sc = np.zeros(k, dtype=np.float64)
+    rounds = C.c_int32(0)
+    ppr = np.zeros(g.n, dtype=np.uint64) if want_ppr else None
+    up = np.zeros(g.n, dtype=np.float64) if want_bounds else None
+    lo = np.zeros(g.n, dtype=np.float64) if want_bounds else None
+    a, b, c = _idx_args(index)
+    lib().orc_twin_topk_bound_query(C.c_int32(g.n), C.c_int64(g.m), _p(g.row_ptr), _p(g.col), C.c_int32(s),
+                                    C.c_int32(k), _d(epsilon), _d(alpha), _d(rmax_scale), _d(ppr_decay_alpha),
+                                    C.c_uint64(seed), a, b, c, _p(ids), _p(sc), C.byref(rounds), _p(ppr), _p(up), _p(lo))
+    return ids, sc, rounds.value, ppr, up, lo
+
+
+def calculate_lambda(rsum, pfail, upper_bound, total_rw_num):
+    f = lib().orc_calculate_lambda
+    f.restype = C.c_double
+    return f(_d(rsum), _d(pfail), _d(upper_bound), C.c_long(total_rw_num))

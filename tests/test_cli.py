@@ -141,9 +141,16 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
     j2 = json.load(open(tmp_path / "res2" / "execution" / "g32k.query.fora.without_idx.k-500.rmax-1.000000.json"))
     j1 = json.load(open(tmp_path / "res" / "execution" / "g32k.query.fora.without_idx.k-500.rmax-1.000000.json"))
     assert j2["result"]["total number of rand-walks"] == j1["result"]["total number of rand-walks"]
-    # topk without --opt is the bounds variant: refused, not silently substituted
-    r = _run([cli, "topk", "--algo", "fora", "--k", "20", *common])
-    assert r.returncode == 1
+    # topk without --opt is the bounds variant (get_topk, query.h:1150-1153), served from the non --opt index
+    r = _run([cli, "topk", "--algo", "fora", "--with_idx", "--k", "20", "--query_size", "3", *common])
+    assert r.returncode == 0, r.stderr
+    lines = open(tmp_path / "res" / "g32k.topk.k-20.txt").read().strip().split("\n")
+    index = oracle.build_index(g, 0x464F5241, rmax, omega, opt=False)
+    ids, sc, _, _, _, _ = oracle.twin_topk_bound_query(g, int(queries[1]), 20, 0.5, seed=0x464F5241, index=index)
+    got = lines[1].split()
+    assert int(got[0]) == queries[1]
+    assert [int(x.split(":")[0]) for x in got[1:]] == ids.tolist()
+    assert [float(x.split(":")[1]) for x in got[1:]] == sc.tolist()
 
 
 @pytest.mark.gpu

@@ -344,3 +344,40 @@ def test_power_iteration_bit_exact_vs_twin(engine, oracle, request, gname):
     import fora_amd
     with pytest.raises(fora_amd.ForaError):
         engine.power_iteration(srcs[:1], max_iter=0)
+
+
+@pytest.mark.parametrize("with_idx", [False, True])
+@pytest.mark.parametrize("k", [20, 500])
+def test_topk_with_bounds_bit_exact_vs_twin(engine, oracle, small_dangling, k, with_idx):
+    """get_topk without --opt (fora_query_topk_with_bound, query.h:909-969): rounds, ids and scores equal the
+    twin's; k = 500 reaches the rounds where set_ppr_bounds / the bound-based stop rule are active."""
+    g = small_dangling
+    eps = 0.5
+    rmax, omega = _load(engine, g, epsilon=eps)
+    index = None
+    if with_idx:
+        engine.build_index()        # the non --opt index (build.h:328 else branch)
+        index = engine.get_index()
+    srcs = np.concatenate([pick_sources(g, 5, 95), pick_sources(g, 1, 96, want_dangling=True)])
+    ids, sc, rounds = engine.topk_bound(srcs, k, epsilon=eps, with_idx=with_idx)
+    for i, s in enumerate(srcs):
+        wid, wsc, wr, _, _, _ = oracle.twin_topk_bound_query(g, int(s), k, eps, seed=SEED, index=index)
+        assert rounds[i] == wr
+        assert (ids[i] == wid).all()
+        assert (sc[i] == wsc).all()
+        if g.deg[s] > 0:
+            exact = oracle.power_iteration(g, int(s))
+            truth = set(np.argsort(-exact)[:k].tolist())
+            assert len(truth & set(ids[i].tolist())) >= int(0.8 * k)
+            rid, rsc, rr, _ = oracle.topk_bound_query(g, int(s), k, eps, seed=SEED, index=index)
+            assert len(set(rid.tolist()) & set(ids[i].tolist())) >= int(0.8 * k) and abs(rr - wr) <= 1
+        else:
+            assert ids[i][0] == s and sc[i][0] == 1.0 and (sc[i][1:] == 0).all() and rounds[i] == 1
+    # other decay exponent (moves `threshold`, query.h:913) and batching in slots of 2
+    engine.set_batch(2)
+    ids2, sc2, r2 = engine.topk_bound(srcs[:3], k, epsilon=eps, ppr_decay_alpha=0.5, with_idx=with_idx)
+    engine.set_batch(0)
+    for i, s in enumerate(srcs[:3]):
+        wid, wsc, wr, _, _, _ = oracle.twin_topk_bound_query(g, int(s), k, eps, ppr_decay_alpha=0.5, seed=SEED, index=index)
+        assert r2[i] == wr and (ids2[i] == wid).all() and (sc2[i] == wsc).all()
+    engine.clear_index()

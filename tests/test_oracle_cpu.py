@@ -221,3 +221,58 @@ def test_power_iteration_families_agree(oracle, request, gname):
             nxt[s] += 0.8 * r[g.deg == 0].sum()
             r = nxt
         assert np.abs(p - want).max() < 1e-12
+
+
+SEED = 0x464F5241
+_GD = {}
+
+
+def oracle_graph_dangling(oracle):
+    if "g" not in _GD:
+        from fora_amd import synth
+        n, m, seed = synth.PRESETS["tiny"]
+        src, dst = synth.rmat_graph(n, m, seed, "rmat")
+        _GD["g"] = oracle.Graph.from_edges(n, m, src, dst)
+    return _GD["g"]
+
+
+def test_topk_with_bounds_families(oracle, small):
+    """get_topk without --opt (query.h:909-969): the reference-order restatement and the twin agree on the round
+    schedule and on (nearly) all of the list, the list is accurate, and the bounds bracket the exact PPR."""
+    g = small
+    eps = 0.5
+    srcs = pick_sources(g, 2, 91)
+    for k in (20, 500):
+        for s in srcs:
+            s = int(s)
+            ids, sc, rounds, _ = oracle.topk_bound_query(g, s, k, eps, seed=SEED)
+            ti, ts, tr, tp, up, lo = oracle.twin_topk_bound_query(g, s, k, eps, seed=SEED, want_ppr=True, want_bounds=True)
+            assert abs(rounds - tr) <= 1
+            assert (np.diff(sc) <= 0).all() and (np.diff(ts) <= 0).all()
+            assert len(set(ids.tolist()) & set(ti.tolist())) >= int(0.9 * k)
+            exact = oracle.power_iteration(g, s)
+            truth = set(np.argsort(-exact)[:k].tolist())
+            assert len(truth & set(ti.tolist())) >= int(0.85 * k)
+            assert len(truth & set(ids.tolist())) >= int(0.85 * k)
+            # bounds hold with probability 1 - pfail per node with pi >= 1/n (the relative bound of
+            # algo.h:1183-1185 assumes pi >= min_ppr)
+            big = exact >= 1.0 / g.n
+            assert (up[big] >= exact[big]).all()
+            assert (lo[big] <= exact[big]).all()
+            assert int(tp.sum()) == oracle.FIX_ONE
+    # k = 500 runs into the rounds below `threshold`, where the bounds are maintained
+    assert (lo > 0).any() and (up < 1).any()
+    # dangling source: one round, ppr = e_s (query.h:951-955)
+    d = int(pick_sources(oracle_graph_dangling(oracle), 1, 92, want_dangling=True)[0])
+    gd = oracle_graph_dangling(oracle)
+    ids, sc, rounds, _ = oracle.topk_bound_query(gd, d, 10, eps, seed=SEED)
+    ti, ts, tr, _, _, _ = oracle.twin_topk_bound_query(gd, d, 10, eps, seed=SEED)
+    assert rounds == tr == 1 and ids[0] == ti[0] == d and sc[0] == ts[0] == 1.0 and (sc[1:] == 0).all()
+
+
+def test_calculate_lambda_operand_order(oracle):
+    """algo.h:1169-1174 against the same expression written in numpy."""
+    rsum, pfail, ub, tot = 0.23, 1e-11, 0.4, 123456
+    L = np.log(2 / pfail)
+    want = 1.0 / 3 * L * rsum / tot + np.sqrt(4.0 / 9.0 * L * L * rsum * rsum + 8 * tot * L * rsum * ub) / 2.0 / tot
+    assert oracle.calculate_lambda(rsum, pfail, ub, tot) == want
