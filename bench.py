@@ -37,9 +37,11 @@ def parse():
     ap.add_argument("--opt", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="queries in flight per launch (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--balanced", action="store_true", help="--balanced of the reference CLI (query.h:848-884), MI355X cost model")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra --balanced timing")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the L-inf check against GPU power iteration")
     ap.add_argument("--topk", type=int, default=0, help="k > 0: time `topk --opt` (config 5 style) instead of `query`")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
@@ -137,6 +139,8 @@ def main():
     rmax, omega = eng.get_params()
     if args.batch:
         eng.set_batch(args.batch)
+    if args.balanced:
+        eng.set_balanced(True)
     t_idx = 0.0
     if args.with_idx:
         t0 = time.perf_counter()
@@ -215,9 +219,9 @@ def main():
                 "workload": f"{args.graph}-sized R-MAT (n={n}, m={m}, dangling={args.dangling}) eps={args.epsilon} "
                             f"query_size={args.queries}/GPU, fora push + "
                             f"{'indexed' if args.with_idx else 'online Philox'} walks"
-                            f"{' --opt' if args.opt else ''} on {world}x MI355X",
+                            f"{' --opt' if args.opt else ''}{' --balanced' if args.balanced else ''} on {world}x MI355X",
                 "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "query_size_per_gpu": args.queries,
-                "with_idx": bool(args.with_idx), "opt": bool(args.opt), "batch": eng.get_batch(),
+                "with_idx": bool(args.with_idx), "opt": bool(args.opt), "balanced": bool(args.balanced), "batch": eng.get_batch(),
                 "sharding": f"sources i mod {world}", "non_dangling_sources": int(tot[1]),
                 "rmax": rmax, "omega": omega, "device": arch, "cus": cus,
             },
@@ -238,6 +242,23 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
         if not args.no_accuracy and not args.opt:
             out["accuracy"] = accuracy(eng, mine, n, args, np)
+        if world == 1 and not args.balanced and not args.no_variants:
+            # the reference's other way to run the same query path (README.md:135): --balanced; not the headline value
+            eng.set_balanced(True)
+            eng.query(mine, with_idx=args.with_idx, want_ppr=False)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                _, stb = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - tb
+            eng.set_balanced(False)
+            assert all(s["ppr_sum_fix"] == 1 << 62 for s in stb)
+            out["variants"] = {"balanced": {
+                "value": len(mine) * args.steps / dtb, "unit": "queries/s",
+                "mean_rmax_ratio": float(np.mean([s["rmax_used"] / rmax for s in stb if not s["dangling_source"]])),
+                "walks_per_query": float(np.mean([s["n_walks"] for s in stb])),
+                "note": "--balanced (query.h:848-884) with the MI355X cost model of fora_hip_set_balanced; same guarantee"}}
         # roofline of the dominant push kernel (k_push_expand): ALGORITHMIC bytes = 24 B per edge
         # relaxation of the sequential FIFO oracle; relaxations the level-synchronous
         # schedule adds on top are not credited.  Duration: HIP events around every launch.

@@ -13,7 +13,7 @@ STREAM_INDEX = 0xFFFFFFFF
 SYMBOLS = [
     "fora_hip_create", "fora_hip_destroy", "fora_hip_device_count", "fora_hip_last_error", "fora_hip_device_info",
     "fora_hip_set_graph", "fora_hip_set_params", "fora_hip_set_params_raw", "fora_hip_get_params",
-    "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_index_sizes", "fora_hip_build_index",
+    "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_set_balanced", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",
     "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_topk_bound_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
     "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing",
@@ -30,7 +30,8 @@ class QueryStats(C.Structure):
     _fields_ = [("rsum", C.c_double), ("rsum_fix", C.c_uint64), ("n_rw", C.c_uint64),
                 ("n_walks", C.c_uint64), ("n_idx_hit", C.c_uint64), ("pops", C.c_uint64),
                 ("relax", C.c_uint64), ("ppr_sum_fix", C.c_uint64), ("levels", C.c_int32),
-                ("dangling_source", C.c_int32)]
+                ("dangling_source", C.c_int32), ("rmax_used", C.c_double), ("push_rounds", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -194,6 +195,11 @@ class Engine:
                                                 C.c_double(rmax_scale), C.c_int(int(with_idx)), _p(ids), _p(sc),
                                                 _p(rounds)))
         return ids, sc, rounds[:nq]
+
+    def set_balanced(self, on=True, c_pop=0.0, c_edge=0.0, t_walk=0.0, t_idx=0.0):
+        """--balanced (query.h:848-884); costs <= 0 select the MI355X defaults."""
+        self._chk(self._lib.fora_hip_set_balanced(self._ctx, C.c_int(int(on)), C.c_double(c_pop), C.c_double(c_edge),
+                                                  C.c_double(t_walk), C.c_double(t_idx)))
 
     def topk_bound(self, sources, k, epsilon=0.5, rmax_scale=1.0, ppr_decay_alpha=0.77, with_idx=False):
         """get_topk without --opt (top-k with bounds, query.h:909-969)."""

@@ -102,6 +102,11 @@ struct fora_ctx {
     // k+1 overlap the (fabric-bound) walks of batch k
     fora_ctx *twin = nullptr;
     bool is_twin = false;
+    // --balanced (query.h:848-884): cost model in seconds
+    bool balanced = false;
+    double c_pop = 1.0e-11, c_edge = 1.2e-11, t_walk = 6.5e-11, t_idx = 2.2e-11;
+    std::vector<double> h_rmax_used;
+    std::vector<int32_t> h_rounds;
     int pending_nq = 0;                      // batch enqueued on this lane, not yet finished
 
     // timing
@@ -517,6 +522,58 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
 // one batch of <= B sources: push (+ refinement).  Results stay in the slabs.
 // one batch of <= B sources, part 1: push (host-driven level loop, returns when the push is done)
 // and everything after it enqueued on the lane's stream.  Results stay in the slabs.
+// --balanced push of a batch (query.h:848-884): rounds of the incremental push (algo.h:1020-1093) with rmax halving
+// from 8*config.rmax; a slot keeps going while its estimated walk cost exceeds what its push has cost so far.
+int push_balanced(fora_ctx *c, const int32_t *sources, int nq, bool with_idx) {
+    if (!c->d_active) HIPCHK(c, hipMalloc(&c->d_active, (size_t)c->B));
+    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    Dev d = make_dev(c, nq, with_idx);
+    int h = ev_begin(c, 4);
+    hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
+    ev_end(c, h);
+    std::vector<uint8_t> active((size_t)nq, 1);
+    std::vector<uint64_t> rsum_fix((size_t)nq, FIX_ONE), pops((size_t)nq, 0), relax((size_t)nq, 0);
+    c->h_rmax_used.assign((size_t)nq, c->rmax);
+    c->h_rounds.assign((size_t)nq, 1);
+    for (int i = 0; i < nq; i++)
+        if (c->h_row_ptr[sources[i] + 1] == c->h_row_ptr[sources[i]]) active[i] = 0; // :864, :882
+    for (int i = 0; i < nq; i++) if (active[i]) c->h_rounds[i] = 0;
+    double rmax = c->rmax * 8; // :862
+    for (int round = 0;; round++) {
+        bool any = false;
+        for (int i = 0; i < nq; i++) {
+            if (!active[i]) continue;
+            const double t = (!with_idx || rmax >= c->rmax) ? c->t_walk : c->t_idx;                       // :825-838
+            const double est = c->omega * std::ldexp((double)rsum_fix[i], -62) * (1 - c->alpha) * t;
+            const double used = (double)pops[i] * c->c_pop + (double)relax[i] * c->c_edge;
+            if (!(est > used)) active[i] = 0;                                                              // :866
+            else { any = true; c->h_rmax_used[i] = rmax; c->h_rounds[i] = round + 1; }
+        }
+        if (!any) break;
+        if (round >= 64) return fail(c, FORA_E_OVERFLOW, "--balanced: rmax halved 64 times");
+        HIPCHK(c, hipMemcpyAsync(c->d_active, active.data(), (size_t)nq, hipMemcpyHostToDevice, c->stream));
+        if (round) {
+            HIPCHK(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
+            int rc = reset_binned_counters(c);
+            if (rc) return rc;
+        }
+        Dev dr = make_dev(c, nq, with_idx, rmax, c->omega);
+        h = ev_begin(c, 4);
+        hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, dr, (const uint8_t *)c->d_active);
+        ev_end(c, h);
+        int rc = run_push_levels(c, dr);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpy(c->h_qs.data(), c->d_qs, (size_t)nq * sizeof(QState), hipMemcpyDeviceToHost));
+        for (int i = 0; i < nq; i++) {
+            rsum_fix[i] = FIX_ONE - c->h_qs[i].reserved;
+            pops[i] = c->h_qs[i].pops;
+            relax[i] = c->h_qs[i].relax;
+        }
+        rmax /= 2; // :875
+    }
+    return FORA_OK;
+}
+
 int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int flags) {
     for (int i = 0; i < nq; i++)
         if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
@@ -524,10 +581,15 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
     int rc = reset_batch_state(c, nq, sources);
     if (rc) return rc;
     Dev d = make_dev(c, nq, with_idx);
-    int h = ev_begin(c, 4);
-    hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 0);
-    ev_end(c, h);
-    rc = run_push_levels(c, d);
+    int h;
+    if (c->balanced) {
+        rc = push_balanced(c, sources, nq, with_idx);
+    } else {
+        h = ev_begin(c, 4);
+        hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 0);
+        ev_end(c, h);
+        rc = run_push_levels(c, d);
+    }
     if (rc) return rc;
     if (!(flags & RUN_PUSH_ONLY)) {
         const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
@@ -579,6 +641,9 @@ void fill_stats(const fora_ctx *c, int nq, fora_query_stats *out) {
         o.n_rw = s.n_rw; o.n_walks = s.n_walks; o.n_idx_hit = s.n_hit;
         o.pops = s.pops; o.relax = s.relax; o.ppr_sum_fix = s.ppr_sum;
         o.levels = (int32_t)s.levels; o.dangling_source = (int32_t)s.dangling_source;
+        o.rmax_used = c->balanced && (size_t)i < c->h_rmax_used.size() ? c->h_rmax_used[i] : c->rmax;
+        o.push_rounds = c->balanced && (size_t)i < c->h_rounds.size() ? c->h_rounds[i] : 1;
+        o.reserved_ = 0;
     }
 }
 
@@ -605,6 +670,7 @@ int sync_twin(fora_ctx *c) {
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
     w->idx_len = c->idx_len; w->have_index = c->have_index;
+    w->balanced = c->balanced; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
     w->batch_req = c->B; // same slot count as the first lane
     return FORA_OK;
 }
@@ -838,6 +904,16 @@ int fora_hip_set_batch(fora_ctx *c, int batch) {
     return FORA_OK;
 }
 int fora_hip_get_batch(fora_ctx *c) { return c ? c->B : FORA_E_ARG; }
+
+int fora_hip_set_balanced(fora_ctx *c, int on, double c_pop, double c_edge, double t_walk, double t_idx) {
+    if (!c) return FORA_E_ARG;
+    c->balanced = on != 0;
+    c->c_pop = c_pop > 0 ? c_pop : 1.0e-11;
+    c->c_edge = c_edge > 0 ? c_edge : 1.2e-11;
+    c->t_walk = t_walk > 0 ? t_walk : 6.5e-11;
+    c->t_idx = t_idx > 0 ? t_idx : 2.2e-11;
+    return FORA_OK;
+}
 
 // ---- index ---------------------------------------------------------------------
 static uint64_t host_index_sizes(const fora_ctx *c, uint64_t *off, uint64_t *cnt) {

@@ -56,6 +56,7 @@ static const char *HELP =
     "  --k <top k>\n"
     "  --with_idx\n"
     "  --opt\n"
+    "  --balanced\n"
     "  --result_dir <directory to place results>\n"
     "  --rmax_scale <scale of rmax>\n"
     "  --seed <walk RNG seed>   (MI355X build: Philox, reproducible)\n"
@@ -218,6 +219,7 @@ static int run_sharded(const Graph &graph, const std::vector<int32_t> &queries, 
             if (fora_hip_set_graph(ctx, graph.n, graph.m, graph.row_ptr.data(), graph.col.data())) return bail("set_graph");
             if (fora_hip_set_params(ctx, config.alpha, config.epsilon, config.rmax_scale, config.opt, config.seed)) return bail("set_params");
             if (config.batch) fora_hip_set_batch(ctx, config.batch);
+            if (config.balanced) fora_hip_set_balanced(ctx, 1, 0, 0, 0, 0); // query.h:848-884, MI355X cost model
             if (index && fora_hip_set_index(ctx, index->rw.data(), index->rw.size(), index->off.data(), index->cnt.data()))
                 return bail("set_index");
             fora_hip_reset_timing(ctx);
@@ -479,7 +481,6 @@ int main(int argc, char *argv[]) {
     }
     info("config.version", config.version);
     info("config.action", config.action);
-    if (config.balanced) { cerr << "--balanced (wall-clock driven rmax, query.h:848-884) is not supported" << endl; return 1; }
 
     const string act = config.action;
     if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH && act != GEN_EXACT_TOPK) {

@@ -48,6 +48,9 @@ typedef struct {
     uint64_t ppr_sum_fix; /* sum of the final ppr vector (== FORA_FIX_ONE when mass is conserved) */
     int32_t levels;      /* push levels this query was active in */
     int32_t dangling_source; /* 1: algo.h:961-965 fast path taken */
+    double rmax_used;    /* rmax of the last push round (config.rmax unless --balanced, query.h:877) */
+    int32_t push_rounds; /* 1 unless --balanced */
+    int32_t reserved_;
 } fora_query_stats;
 
 /* Accumulated device timings since the last reset (HIP events on the ctx stream). */
@@ -95,6 +98,13 @@ int fora_hip_set_params(fora_ctx *ctx, double alpha, double epsilon, double rmax
 int fora_hip_set_params_raw(fora_ctx *ctx, double alpha, double rmax, double omega, int opt,
                             uint64_t seed);
 int fora_hip_get_params(fora_ctx *ctx, double *rmax, double *omega);
+/* --balanced (config.balanced; fora_query_basic query.h:848-884, estimated_random_walk_cost :825-838): rmax is
+ * halved from 8*rmax while the estimated walk cost omega*rsum*(1-alpha)*t exceeds what the push has cost so far.
+ * The reference measures the push with a wall clock (not reproducible); here it is charged by its work counters,
+ * pops*c_pop + relax*c_edge seconds, and t = t_walk (t_idx with an index once rmax < config.rmax).  A cost <= 0
+ * selects the value measured on MI355X (1.0e-11, 1.2e-11, 6.5e-11, 2.2e-11 s; the reference's constants are
+ * t_walk = 4e-7, t_idx = t_walk/140, query.h:822-823). */
+int fora_hip_set_balanced(fora_ctx *ctx, int on, double c_pop, double c_edge, double t_walk, double t_idx);
 /* queries processed concurrently per launch; 0 = choose from free HBM */
 int fora_hip_set_batch(fora_ctx *ctx, int batch);
 int fora_hip_get_batch(fora_ctx *ctx);

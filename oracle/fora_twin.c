@@ -505,3 +505,62 @@ int orc_twin_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, cons
     free(upper); free(lower); free(tb); free(filter);
     return 0;
 }
+
+/* ---- --balanced (fora_query_basic, query.h:848-884) in the twin's schedule --------------------------------------
+ * The reference halves rmax from 8*config.rmax while the estimated walk cost (query.h:825-838) exceeds the
+ * wall-clock time the push has taken so far.  Wall-clock is not reproducible; this build charges the push by its
+ * work counters instead: used = pops*c_pop + relax*c_edge (seconds), and keeps the reference's walk estimate
+ * omega*rsum*(1-alpha)*t_walk (t_idx once rmax < config.rmax with an index).  Rounds are incremental pushes from
+ * every node at/over the round's threshold, as in the top-k driver.  Returns the number of rounds; *rmax_out =
+ * the last rmax pushed with. */
+int orc_twin_query_balanced(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax0,
+                            double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                            const uint64_t *off, const uint64_t *cnt, double c_pop, double c_edge, double t_walk,
+                            double t_idx, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *pst,
+                            orc_refine_stats *rst, double *rmax_out) {
+    orc_twin_push_stats z = {0, 0, 0, 0};
+    memset(residue, 0, sizeof(uint64_t) * (size_t)n);
+    memset(ppr, 0, sizeof(uint64_t) * (size_t)n);
+    int rounds = 0;
+    double rmax = rmax0 * 8; /* query.h:862 */
+    if (row_ptr[s + 1] == row_ptr[s]) { /* :864, :882: plain push of a dangling source */
+        ppr[s] = ORC_FIX_ONE;
+        z.rsum_fix = 0;
+        rmax = rmax0;
+    } else {
+        int32_t *frontier = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+        int32_t *next = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+        uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+        uint64_t afix = orc_twin_alpha_fix(alpha);
+        residue[s] = ORC_FIX_ONE;
+        uint64_t rsum_fix = ORC_FIX_ONE;
+        double used = 0;
+        for (;;) {
+            const double t = (!rw_idx || rmax >= rmax0) ? t_walk : t_idx;              /* query.h:825-838 */
+            const double est = omega * fix2d(rsum_fix) * (1 - alpha) * t;
+            if (!(est > used)) break;                                                  /* :866 */
+            uint64_t t1 = orc_twin_rmax_fix(rmax);
+            int64_t fn = 0;
+            for (int32_t v = 0; v < n; v++)
+                if (residue[v] && residue[v] >= node_thr(t1, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
+            orc_twin_push_stats ps = {0, 0, 0, 0};
+            twin_levels(row_ptr, col, s, t1, afix, residue, ppr, frontier, fn, next, inc, &ps, NULL, 0, 0);
+            z.levels += ps.levels; z.pops += ps.pops; z.relax += ps.relax;
+            used = (double)z.pops * c_pop + (double)z.relax * c_edge;                  /* :870-872, by counters */
+            uint64_t reserved = 0;
+            for (int32_t v = 0; v < n; v++) reserved += ppr[v];
+            rsum_fix = ORC_FIX_ONE - reserved;
+            rounds++;
+            rmax /= 2;                                                                 /* :875 */
+        }
+        rmax *= 2;                                                                     /* :877 */
+        z.rsum_fix = rsum_fix;
+        free(frontier); free(next); free(inc);
+    }
+    orc_refine_stats rs = {0, 0, 0};
+    orc_twin_refine(n, row_ptr, col, s, residue, z.rsum_fix, omega, alpha, opt, seed, rw_idx, off, cnt, ppr, &rs);
+    if (pst) *pst = z;
+    if (rst) *rst = rs;
+    if (rmax_out) *rmax_out = rmax;
+    return rounds;
+}

@@ -116,6 +116,12 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
         walks = sum(oracle.twin_query(g, int(s), rmax, omega, seed=0x464F5241)[2]["n_walks"] for s in queries[:10])
         assert float(j["result"]["total number of rand-walks"]) == walks
         assert set(j["timer"]) >= {"3", "5", "6"}
+    # --balanced (README.md:135 "TODS version"): adaptive rmax, same outputs; walk total equals the twin's
+    r = _run([cli, "query", "--algo", "fora", "--balanced", "--query_size", "4", "--result_dir", str(tmp_path / "resb"), *common[:6]])
+    assert r.returncode == 0, r.stderr
+    jb = json.load(open(tmp_path / "resb" / "execution" / "g32k.query.fora.without_idx.k-500.rmax-1.000000.json"))
+    walks_b = sum(oracle.twin_query_balanced(g, int(s), rmax, omega, seed=0x464F5241)[2]["n_walks"] for s in queries[:4])
+    assert float(jb["result"]["total number of rand-walks"]) == walks_b
     # build --opt + topk --opt --with_idx
     r = _run([cli, "build", "--opt", *common])
     assert r.returncode == 0 and os.path.exists(folder / "randwalks.idx.onehopopt")

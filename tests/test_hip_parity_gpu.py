@@ -381,3 +381,42 @@ def test_topk_with_bounds_bit_exact_vs_twin(engine, oracle, small_dangling, k, w
         wid, wsc, wr, _, _, _ = oracle.twin_topk_bound_query(g, int(s), k, eps, ppr_decay_alpha=0.5, seed=SEED, index=index)
         assert r2[i] == wr and (ids2[i] == wid).all() and (sc2[i] == wsc).all()
     engine.clear_index()
+
+
+@pytest.mark.parametrize("with_idx", [False, True])
+def test_balanced_bit_exact_vs_twin(engine, oracle, small_dangling, with_idx):
+    """--balanced (fora_query_basic query.h:848-884 with the push charged by its work counters): rmax schedule, push
+    state and refined ppr equal the twin's; the answer still honours the epsilon guarantee."""
+    g = small_dangling
+    rmax, omega = _load(engine, g, epsilon=0.5)
+    index = None
+    if with_idx:
+        engine.build_index()
+        index = engine.get_index()
+    srcs = np.concatenate([pick_sources(g, 6, 97), pick_sources(g, 1, 98, want_dangling=True)])
+    engine.set_balanced(True)
+    try:
+        ppr, res, st = engine.query_fix(srcs, with_idx=with_idx)
+        engine.set_batch(3)
+        ppr3, res3, st3 = engine.query_fix(srcs, with_idx=with_idx)
+        engine.set_batch(0)
+    finally:
+        engine.set_balanced(False)
+    assert (ppr3 == ppr).all() and (res3 == res).all()
+    for i, s in enumerate(srcs):
+        want, wres, wst = oracle.twin_query_balanced(g, int(s), rmax, omega, seed=SEED, index=index)
+        assert (res[i] == wres).all() and (ppr[i] == want).all()
+        assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["n_walks"] == wst["n_walks"]
+        assert st[i]["ppr_sum_fix"] == oracle.FIX_ONE
+        if g.deg[s] > 0:
+            assert st[i]["push_rounds"] == wst["rounds"] >= 2 and st[i]["rmax_used"] == wst["rmax"]
+            exact = oracle.power_iteration(g, int(s))
+            big = exact >= 1.0 / g.n
+            est = oracle.fix_to_double(ppr[i])
+            assert (np.abs(est - exact)[big] / exact[big]).max() <= 0.5
+        else:
+            assert st[i]["dangling_source"] == 1 and st[i]["rmax_used"] == rmax
+    # plain mode reports one round at config.rmax
+    _, _, st = engine.query_fix(srcs[:2])
+    assert all(s["push_rounds"] == 1 and s["rmax_used"] == rmax for s in st)
+    engine.clear_index()

@@ -276,3 +276,24 @@ def test_calculate_lambda_operand_order(oracle):
     L = np.log(2 / pfail)
     want = 1.0 / 3 * L * rsum / tot + np.sqrt(4.0 / 9.0 * L * L * rsum * rsum + 8 * tot * L * rsum * ub) / 2.0 / tot
     assert oracle.calculate_lambda(rsum, pfail, ub, tot) == want
+
+
+def test_twin_balanced_mode(oracle, small):
+    """--balanced in the twin: conserves mass, keeps the guarantee, ends at a smaller rmax with fewer walks than
+    the plain run when walks are the expensive side, and degenerates to 8*rmax when they are free."""
+    g = small
+    rmax, omega = oracle.fora_setting(g.n, g.m, 0.5)
+    for s in pick_sources(g, 2, 93):
+        s = int(s)
+        ppr0, _, st0 = oracle.twin_query(g, s, rmax, omega, seed=SEED)
+        ppr, res, st = oracle.twin_query_balanced(g, s, rmax, omega, seed=SEED)
+        assert int(ppr.sum()) == oracle.FIX_ONE
+        assert st["rounds"] >= 2 and st["rmax"] == rmax * 8 / 2 ** (st["rounds"] - 1)
+        exact = oracle.power_iteration(g, s)
+        big = exact >= 1.0 / g.n
+        est = oracle.fix_to_double(ppr)
+        assert (np.abs(est - exact)[big] / exact[big]).max() <= 0.5
+        if st["rmax"] < rmax:
+            assert st["n_walks"] < st0["n_walks"] and st["relax"] > st0["relax"]
+        _, _, free = oracle.twin_query_balanced(g, s, rmax, omega, seed=SEED, t_walk=1e-30)
+        assert free["rounds"] == 1 and free["rmax"] == rmax * 8

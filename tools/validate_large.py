@@ -56,3 +56,23 @@ print(f"{len(srcs)} indexed queries: {dt:.2f} s = {len(srcs) / dt:.2f} queries/s
       f"idx hit = {sum(s['n_idx_hit'] for s in st) == sum(s['n_walks'] for s in st)}")
 print("per query: relax %.3g walks %.3g levels %.0f; phases ms:" % (tm["relax"] / len(srcs), tm["walks"] / len(srcs), tm["levels"]),
       {k: round(v, 1) for k, v in tm.items() if k.endswith("_ms")})
+
+# config 5 style: top-k (k = 500, --opt, --with_idx) on the same graph
+if len(sys.argv) > 5 and sys.argv[5] == "topk":
+    e.clear_index()
+    e.set_params(epsilon=0.5, opt=True, seed=7)
+    t0 = time.time()
+    e.build_index()
+    total, _, _ = e.index_sizes()
+    print(f"--opt index: {total} walks built in {time.time() - t0:.2f} s", flush=True)
+    nk = min(len(srcs), 8)
+    e.topk(srcs[:2], 500, epsilon=0.5, with_idx=True)  # warm-up
+    e.reset_timing()
+    t0 = time.time()
+    ids, sc, rounds = e.topk(srcs[:nk], 500, epsilon=0.5, with_idx=True)
+    dt = time.time() - t0
+    tm = e.timing()
+    assert (np.diff(sc, axis=1) <= 0).all() and (sc[:, 0] > 0).all()
+    print(f"{nk} top-k queries (k=500 --opt --with_idx): {dt:.2f} s = {nk / dt:.2f} queries/s, rounds {rounds.tolist()}, "
+          f"idx hit ratio {tm['idx_hits'] / max(1, tm['walks']):.3f}")
+    print("phases ms:", {k: round(v, 1) for k, v in tm.items() if k.endswith("_ms")})
