@@ -88,6 +88,7 @@ struct fora_ctx {
     uint8_t *d_filter = nullptr;
     uint32_t *d_fail = nullptr;
     unsigned long long *d_round_walks = nullptr;
+    uint32_t *d_nz_counts = nullptr; // [B][NZ_X + 1]: per-block non-zero counts, then the slot's total
     double *d_lb_sc = nullptr;
     int32_t *d_lb_ids = nullptr;
     int lb_cap = 0;
@@ -152,6 +153,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     dfree(c->d_upper); dfree(c->d_lower); dfree(c->d_filter); dfree(c->d_fail); dfree(c->d_round_walks);
     dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
+    dfree(c->d_nz_counts);
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
@@ -467,6 +469,30 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
         if (e != hipSuccess) rc = fail(c, FORA_E_HIP, std::string("push launch: ") + hipGetErrorString(e));
     }
     return rc;
+}
+
+// k_topk_select over the slabs of `ds.ppr`; large graphs first compact each slot's non-zero entries (in id order, so
+// ties keep resolving to the lowest ids) into the push's frontier / increment buffers, which are idle here.
+constexpr unsigned NZ_X = 1024;
+int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, double *scores, int raw) {
+    const char *e = getenv("FORA_HIP_SELECT_COMPACT"); // tests: force (1) or forbid (0) the compacted form
+    bool compact = c->binned && c->n >= (1 << 20);
+    if (e) compact = c->binned && e[0] == '1';
+    if (!compact) {
+        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, ids, scores, raw,
+                           (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr);
+        return FORA_OK;
+    }
+    if (!c->d_nz_counts) HIPCHK(c, hipMalloc(&c->d_nz_counts, (size_t)c->B * (NZ_X + 1) * 4));
+    const unsigned X = (unsigned)std::min<uint64_t>(NZ_X, ((uint64_t)c->n + 4095) / 4096);
+    const uint32_t R = (uint32_t)(((uint64_t)c->n + X - 1) / X);
+    uint32_t *ccount = c->d_nz_counts + (size_t)c->B * NZ_X;
+    hipLaunchKernelGGL(k_nz_count, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, c->d_nz_counts);
+    hipLaunchKernelGGL(k_nz_write, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, (const uint32_t *)c->d_nz_counts, c->d_fl[0],
+                       c->d_inc_tab, ccount);
+    hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, ids, scores, raw,
+                       (const uint32_t *)c->d_fl[0], (const uint64_t *)c->d_inc_tab, (const uint32_t *)ccount);
+    return FORA_OK;
 }
 
 // per-level bookkeeping of the bucketed push that must start from zero
@@ -1185,7 +1211,8 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
         Dev ds = make_dev(c, nb, false);
         ds.ppr = c->d_ppr2;
         int h = ev_begin(c, 4);
-        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc, 0);
+        rc = launch_select(c, ds, nb, k, c->d_topk_ids, c->d_topk_sc, 0);
+        if (rc) return rc;
         ev_end(c, h);
         ev_end(c, hb);
         HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1328,7 +1355,8 @@ int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k
             if (bounds_on) {
                 Dev dl = dw;
                 dl.ppr = (uint64_t *)c->d_lower; // non-negative f64: bit patterns order like the values
-                hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, dl, k, c->d_lb_ids, c->d_lb_sc, 1);
+                rc = launch_select(c, dl, nb, k, c->d_lb_ids, c->d_lb_sc, 1);
+                if (rc) return rc;
                 hipLaunchKernelGGL(k_bound_ratio, dim3(nb), dim3(SEL_THREADS), 0, c->stream, dw, k, (const int32_t *)c->d_lb_ids,
                                    (const double *)c->d_lb_sc, (const uint8_t *)c->d_active, (const double *)c->d_upper,
                                    1.0 + epsilon, c->d_filter, c->d_fail);
@@ -1354,7 +1382,8 @@ int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k
         Dev ds = make_dev(c, nb, false);
         ds.ppr = c->d_ppr2;
         int h = ev_begin(c, 4);
-        hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, c->d_topk_ids, c->d_topk_sc, 0);
+        rc = launch_select(c, ds, nb, k, c->d_topk_ids, c->d_topk_sc, 0);
+        if (rc) return rc;
         ev_end(c, h);
         ev_end(c, hb);
         HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1408,7 +1437,8 @@ int fora_hip_power_iteration_batch(fora_ctx *c, const int32_t *sources, int nq, 
         if (rc) return rc;
         if (want_topk) {
             int h = ev_begin(c, 4);
-            hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, d, k, c->d_topk_ids, c->d_topk_sc, 0);
+            rc = launch_select(c, d, nb, k, c->d_topk_ids, c->d_topk_sc, 0);
+            if (rc) return rc;
             ev_end(c, h);
             HIPCHK(c, hipMemcpyAsync(ids + (size_t)b0 * k, c->d_topk_ids, (size_t)nb * k * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(scores + (size_t)b0 * k, c->d_topk_sc, (size_t)nb * k * 8, hipMemcpyDeviceToHost, c->stream));

@@ -956,9 +956,57 @@ __global__ void __launch_bounds__(BLOCK) k_count_above(Dev d, const uint8_t *act
 // select of the k-th value (LDS histograms), ordered compaction, bitonic sort in LDS.
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAXK = 1024;
+// ordered compaction of a slot's non-zero ppr entries for k_topk_select: block x of slot q owns the contiguous
+// node range [x*R, (x+1)*R).  grid = (X, nq), X <= 1024.
+__global__ void __launch_bounds__(BLOCK) k_nz_count(Dev d, uint32_t R, uint32_t *counts) {
+    __shared__ uint32_t s_w[4];
+    const int q = blockIdx.y;
+    const uint64_t *p = d.ppr + (uint64_t)q * d.n;
+    const uint32_t lo = blockIdx.x * R, hi = min((uint32_t)d.n, lo + R);
+    uint32_t c = 0;
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += BLOCK) c += p[v] != 0;
+    uint32_t tot;
+    (void)block_excl_scan(c, s_w, tot);
+    if (threadIdx.x == 0) counts[(uint64_t)q * gridDim.x + blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(BLOCK) k_nz_write(Dev d, uint32_t R, const uint32_t *counts, uint32_t *cids,
+                                                    uint64_t *ckeys, uint32_t *ccount) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    const int q = blockIdx.y;
+    const uint64_t *p = d.ppr + (uint64_t)q * d.n;
+    uint32_t part = 0;
+    for (uint32_t x = threadIdx.x; x < blockIdx.x; x += BLOCK) part += counts[(uint64_t)q * gridDim.x + x];
+    uint32_t before;
+    (void)block_excl_scan(part, s_w, before);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base = before;
+        if (blockIdx.x == gridDim.x - 1) ccount[q] = before + counts[(uint64_t)q * gridDim.x + blockIdx.x];
+    }
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * R, hi = min((uint32_t)d.n, lo + R);
+    uint32_t base = s_base;
+    for (uint32_t v0 = lo; v0 < hi; v0 += BLOCK) {
+        const uint32_t v = v0 + threadIdx.x;
+        const uint64_t x = v < hi ? p[v] : 0;
+        uint32_t tot;
+        __syncthreads();
+        const uint32_t off = block_excl_scan(x != 0 ? 1u : 0u, s_w, tot);
+        if (x) {
+            cids[(uint64_t)q * d.n + base + off] = v;
+            ckeys[(uint64_t)q * d.n + base + off] = x;
+        }
+        base += tot;
+    }
+}
+
 // raw != 0: the slab holds non-negative f64 (lower bounds; their bit patterns order like the values) and the
 // scores are those doubles.
-__global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32_t *ids, double *scores, int raw) {
+// cids != null: the slot's non-zero entries were compacted in id order by k_nz_count / k_nz_write (large graphs: one
+// block re-reading a 40 M-entry slab ten times costs 50 ms per 10 M nodes; the compacted list is ~1 % of it).
+__global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32_t *ids, double *scores, int raw,
+                                                             const uint32_t *cids, const uint64_t *ckeys, const uint32_t *ccount) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint64_t s_key[SEL_MAXK];
     __shared__ uint32_t s_id[SEL_MAXK];
@@ -966,8 +1014,9 @@ __global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32
     __shared__ uint64_t s_prefix;
     __shared__ uint32_t s_need, s_base_gt, s_base_eq;
     const int q = blockIdx.x;
-    const uint64_t *p = d.ppr + (uint64_t)q * d.n;
-    const uint32_t n = (uint32_t)d.n;
+    const uint64_t *p = cids ? ckeys + (uint64_t)q * d.n : d.ppr + (uint64_t)q * d.n;
+    const uint32_t *pid = cids ? cids + (uint64_t)q * d.n : nullptr;
+    const uint32_t n = cids ? ccount[q] : (uint32_t)d.n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // ---- radix select: value of the k-th largest (0 if fewer than k positive entries)
     if (tid == 0) { s_prefix = 0; s_need = (uint32_t)k; }
@@ -1016,7 +1065,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32
             tg += c & 0xFFFF; te += c >> 16;
         }
         const uint32_t bg = s_base_gt, be = s_base_eq;
-        if (gt) { const uint32_t pos = bg + og + rg; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = v; } }
+        if (gt) { const uint32_t pos = bg + og + rg; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = pid ? pid[v] : v; } }
         __syncthreads();
         if (tid == 0) { s_base_gt = bg + tg; s_base_eq = be + te; }
         (void)re; (void)oe;
@@ -1039,7 +1088,7 @@ __global__ void __launch_bounds__(SEL_THREADS) k_topk_select(Dev d, int k, int32
         const uint32_t be = s_base_eq;
         if (eq) {
             const uint32_t rank = be + oe + re;
-            if (rank < need_eq) { const uint32_t pos = n_gt_total + rank; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = v; } }
+            if (rank < need_eq) { const uint32_t pos = n_gt_total + rank; if (pos < (uint32_t)SEL_MAXK) { s_key[pos] = x; s_id[pos] = pid ? pid[v] : v; } }
         }
         __syncthreads();
         if (tid == 0) s_base_eq = be + te;

@@ -420,3 +420,23 @@ def test_balanced_bit_exact_vs_twin(engine, oracle, small_dangling, with_idx):
     _, _, st = engine.query_fix(srcs[:2])
     assert all(s["push_rounds"] == 1 and s["rmax_used"] == rmax for s in st)
     engine.clear_index()
+
+
+def test_topk_select_compacted_form_same_lists(engine, oracle, small_dangling, monkeypatch):
+    """Large graphs select the top k from an id-ordered compaction of each slot's non-zero entries; forced on a
+    small graph it must give the very same lists (ties included) as the dense scan, in all three callers."""
+    g = small_dangling
+    _load(engine, g, epsilon=0.5, opt=True)
+    srcs = np.concatenate([pick_sources(g, 5, 99), pick_sources(g, 1, 100, want_dangling=True)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FORA_HIP_SELECT_COMPACT", mode)
+        out[mode] = (engine.topk(srcs, 300, epsilon=0.5), engine.topk_bound(srcs, 300, epsilon=0.5),
+                     engine.power_iteration(srcs, max_iter=3, k=700, want_ppr=False)[2:])
+    monkeypatch.delenv("FORA_HIP_SELECT_COMPACT")
+    for a, b in zip(out["0"], out["1"]):
+        for x, y in zip(a, b):
+            assert (np.asarray(x) == np.asarray(y)).all()
+    # 3 iterations from a source reach few nodes: lists are zero-padded and tie-heavy (equal shares of one push)
+    ids, sc = out["1"][2]
+    assert (sc[:, -1] == 0).any() or (np.diff(sc, axis=1) == 0).any()
