@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="queries in flight per launch (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--balanced", action="store_true", help="--balanced of the reference CLI (query.h:848-884), MI355X cost model")
+    ap.add_argument("--balanced-start", type=float, default=1.0, help="first rmax of --balanced as a multiple of rmax (reference: 8)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
@@ -140,7 +141,7 @@ def main():
     if args.batch:
         eng.set_batch(args.batch)
     if args.balanced:
-        eng.set_balanced(True)
+        eng.set_balanced(True, start_scale=args.balanced_start)
     t_idx = 0.0
     if args.with_idx:
         t0 = time.perf_counter()
@@ -244,7 +245,7 @@ def main():
             out["accuracy"] = accuracy(eng, mine, n, args, np)
         if world == 1 and not args.balanced and not args.no_variants:
             # the reference's other way to run the same query path (README.md:135): --balanced; not the headline value
-            eng.set_balanced(True)
+            eng.set_balanced(True, start_scale=args.balanced_start)
             eng.query(mine, with_idx=args.with_idx, want_ppr=False)
             torch.cuda.synchronize()
             tb = time.perf_counter()
@@ -258,6 +259,7 @@ def main():
                 "value": len(mine) * args.steps / dtb, "unit": "queries/s",
                 "mean_rmax_ratio": float(np.mean([s["rmax_used"] / rmax for s in stb if not s["dangling_source"]])),
                 "walks_per_query": float(np.mean([s["n_walks"] for s in stb])),
+                "start_scale": args.balanced_start,
                 "note": "--balanced (query.h:848-884) with the MI355X cost model of fora_hip_set_balanced; same guarantee"}}
         # roofline of the dominant push kernel (k_push_expand): ALGORITHMIC bytes = 24 B per edge
         # relaxation of the sequential FIFO oracle; relaxations the level-synchronous

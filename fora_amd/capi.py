@@ -196,10 +196,10 @@ class Engine:
                                                 _p(rounds)))
         return ids, sc, rounds[:nq]
 
-    def set_balanced(self, on=True, c_pop=0.0, c_edge=0.0, t_walk=0.0, t_idx=0.0):
-        """--balanced (query.h:848-884); costs <= 0 select the MI355X defaults."""
-        self._chk(self._lib.fora_hip_set_balanced(self._ctx, C.c_int(int(on)), C.c_double(c_pop), C.c_double(c_edge),
-                                                  C.c_double(t_walk), C.c_double(t_idx)))
+    def set_balanced(self, on=True, start_scale=0.0, c_pop=0.0, c_edge=0.0, t_walk=0.0, t_idx=0.0):
+        """--balanced (query.h:848-884); costs <= 0 select the MI355X defaults, start_scale <= 0 the reference's 8."""
+        self._chk(self._lib.fora_hip_set_balanced(self._ctx, C.c_int(int(on)), C.c_double(start_scale), C.c_double(c_pop),
+                                                  C.c_double(c_edge), C.c_double(t_walk), C.c_double(t_idx)))
 
     def topk_bound(self, sources, k, epsilon=0.5, rmax_scale=1.0, ppr_decay_alpha=0.77, with_idx=False):
         """get_topk without --opt (top-k with bounds, query.h:909-969)."""

@@ -105,7 +105,7 @@ struct fora_ctx {
     bool is_twin = false;
     // --balanced (query.h:848-884): cost model in seconds
     bool balanced = false;
-    double c_pop = 1.0e-11, c_edge = 1.2e-11, t_walk = 6.5e-11, t_idx = 2.2e-11;
+    double c_pop = 2.0e-11, c_edge = 2.4e-11, t_walk = 6.5e-11, t_idx = 2.2e-11, bal_start = 8;
     std::vector<double> h_rmax_used;
     std::vector<int32_t> h_rounds;
     int pending_nq = 0;                      // batch enqueued on this lane, not yet finished
@@ -347,6 +347,8 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.row_split = c->d_row_split;
     d.npass = c->pbins > 0 ? (c->nbins + c->pbins - 1) / c->pbins : 1;
     d.pass = 0;
+    d.tiny_max = 512; // ws: accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193
+    if (const char *e = getenv("FORA_HIP_TINY")) if (atoi(e) >= 0) d.tiny_max = (uint32_t)atoi(e);
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
     d.inc_tab = c->d_inc_tab; d.segq_cap = c->segq_cap;
@@ -564,7 +566,7 @@ int push_balanced(fora_ctx *c, const int32_t *sources, int nq, bool with_idx) {
     for (int i = 0; i < nq; i++)
         if (c->h_row_ptr[sources[i] + 1] == c->h_row_ptr[sources[i]]) active[i] = 0; // :864, :882
     for (int i = 0; i < nq; i++) if (active[i]) c->h_rounds[i] = 0;
-    double rmax = c->rmax * 8; // :862
+    double rmax = c->rmax * c->bal_start; // :862
     for (int round = 0;; round++) {
         bool any = false;
         for (int i = 0; i < nq; i++) {
@@ -696,7 +698,7 @@ int sync_twin(fora_ctx *c) {
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
     w->idx_len = c->idx_len; w->have_index = c->have_index;
-    w->balanced = c->balanced; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
+    w->balanced = c->balanced; w->bal_start = c->bal_start; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
     w->batch_req = c->B; // same slot count as the first lane
     return FORA_OK;
 }
@@ -931,11 +933,12 @@ int fora_hip_set_batch(fora_ctx *c, int batch) {
 }
 int fora_hip_get_batch(fora_ctx *c) { return c ? c->B : FORA_E_ARG; }
 
-int fora_hip_set_balanced(fora_ctx *c, int on, double c_pop, double c_edge, double t_walk, double t_idx) {
+int fora_hip_set_balanced(fora_ctx *c, int on, double start_scale, double c_pop, double c_edge, double t_walk, double t_idx) {
     if (!c) return FORA_E_ARG;
     c->balanced = on != 0;
-    c->c_pop = c_pop > 0 ? c_pop : 1.0e-11;
-    c->c_edge = c_edge > 0 ? c_edge : 1.2e-11;
+    c->bal_start = start_scale > 0 ? start_scale : 8;
+    c->c_pop = c_pop > 0 ? c_pop : 2.0e-11;
+    c->c_edge = c_edge > 0 ? c_edge : 2.4e-11;
     c->t_walk = t_walk > 0 ? t_walk : 6.5e-11;
     c->t_idx = t_idx > 0 ? t_idx : 2.2e-11;
     return FORA_OK;

@@ -114,6 +114,7 @@ struct Dev {
     const int32_t *col_push;   // == col when there is one pass
     const uint32_t *row_split; // [n][npass + 1] or null
     int32_t npass, pass;
+    uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
     uint64_t *inc_tab;      // [slot][segq_cap] increment of the node at frontier position i (gathered by k_accum)
@@ -691,29 +692,34 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
     const uint64_t bk0 = (uint64_t)bi * d.bk_cap;
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
-    if (ovn == 0 && cnt + (dm ? 1 : 0) <= ACC_THREADS / 4) {
-        // tiny bucket: zeroing and sweeping 64 KiB of LDS would cost more than a few atomics
-        bool cross = false;
-        uint32_t w = 0;
-        uint64_t inc = 0;
-        if (threadIdx.x < cnt) {
-            w = d.bk_w[bk0 + threadIdx.x];
-            if (TO_PPR) inc = d.bk_inc[bk0 + threadIdx.x];
-            else if (d.wide) { inc = d.bk_inc[bk0 + threadIdx.x]; w = node0 + w; }
-            else {
-                inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
-                w = node0 + (w >> SEG_BITS);
+    if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
+        // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
+        // node range and the level's pops are done, so nothing else touches these words)
+        const uint32_t total = cnt + (dm ? 1 : 0);
+        for (uint32_t i0 = 0; i0 < total; i0 += ACC_THREADS) {
+            const uint32_t i = i0 + threadIdx.x;
+            bool cross = false;
+            uint32_t w = 0;
+            uint64_t inc = 0;
+            if (i < cnt) {
+                w = d.bk_w[bk0 + i];
+                if (TO_PPR) inc = d.bk_inc[bk0 + i];
+                else if (d.wide) { inc = d.bk_inc[bk0 + i]; w = node0 + w; }
+                else {
+                    inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
+                    w = node0 + (w >> SEG_BITS);
+                }
+            } else if (i == cnt && dm) { w = s; inc = dm; }
+            if (inc) {
+                const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
+                if (!TO_PPR) {
+                    const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                    cross = old < thr && old + inc >= thr;
+                }
             }
-        } else if (threadIdx.x == cnt && dm) { w = s; inc = dm; }
-        if (inc) {
-            const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
-            if (!TO_PPR) {
-                const uint64_t thr = node_thr(d.t1, d.deg[w]);
-                cross = old < thr && old + inc >= thr;
-            }
+            if (!TO_PPR && i0 + (threadIdx.x & ~63u) < total) // whole waves only
+                wave_append32(cross, w, fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
         }
-        if (!TO_PPR && threadIdx.x < ACC_THREADS / 4 + 64) // whole waves only
-            wave_append32(cross, w, fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
         return;
     }
     for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;

@@ -52,6 +52,7 @@ struct Config { // config.h:86-160
     uint64_t seed = 0x464F5241ull;
     int device = 0;
     int batch = 0;
+    double balanced_start = 0; // --balanced_start S: first rmax of --balanced = S * rmax (0: the reference's 8)
     int gpus = 1;   // --gpus N: sources i mod N on GPU (device + i mod N), one host thread per GPU
     std::string get_graph_folder() const { return prefix + graph_alias + "/"; } // config.h:99-101
 };

@@ -219,7 +219,7 @@ static int run_sharded(const Graph &graph, const std::vector<int32_t> &queries, 
             if (fora_hip_set_graph(ctx, graph.n, graph.m, graph.row_ptr.data(), graph.col.data())) return bail("set_graph");
             if (fora_hip_set_params(ctx, config.alpha, config.epsilon, config.rmax_scale, config.opt, config.seed)) return bail("set_params");
             if (config.batch) fora_hip_set_batch(ctx, config.batch);
-            if (config.balanced) fora_hip_set_balanced(ctx, 1, 0, 0, 0, 0); // query.h:848-884, MI355X cost model
+            if (config.balanced) fora_hip_set_balanced(ctx, 1, config.balanced_start, 0, 0, 0, 0); // query.h:848-884, MI355X cost model
             if (index && fora_hip_set_index(ctx, index->rw.data(), index->rw.size(), index->off.data(), index->cnt.data()))
                 return bail("set_index");
             fora_hip_reset_timing(ctx);
@@ -473,6 +473,7 @@ int main(int argc, char *argv[]) {
         else if (arg == "--dataset") config.graph_alias = next("--dataset");
         else if (arg == "--opt") config.opt = true;
         else if (arg == "--balanced") config.balanced = true;
+        else if (arg == "--balanced_start") config.balanced_start = atof(next("--balanced_start"));
         else if (arg == "--seed") config.seed = strtoull(next("--seed"), nullptr, 0);
         else if (arg == "--device") config.device = atoi(next("--device"));
         else if (arg == "--batch") config.batch = atoi(next("--batch"));

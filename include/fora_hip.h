@@ -102,9 +102,13 @@ int fora_hip_get_params(fora_ctx *ctx, double *rmax, double *omega);
  * halved from 8*rmax while the estimated walk cost omega*rsum*(1-alpha)*t exceeds what the push has cost so far.
  * The reference measures the push with a wall clock (not reproducible); here it is charged by its work counters,
  * pops*c_pop + relax*c_edge seconds, and t = t_walk (t_idx with an index once rmax < config.rmax).  A cost <= 0
- * selects the value measured on MI355X (1.0e-11, 1.2e-11, 6.5e-11, 2.2e-11 s; the reference's constants are
- * t_walk = 4e-7, t_idx = t_walk/140, query.h:822-823). */
-int fora_hip_set_balanced(fora_ctx *ctx, int on, double c_pop, double c_edge, double t_walk, double t_idx);
+ * selects the value calibrated on MI355X (2.0e-11, 2.4e-11, 6.5e-11, 2.2e-11 s: twice the bulk push rate, because
+ * the deeper rounds are long cascades of small levels; the reference's constants are
+ * t_walk = 4e-7, t_idx = t_walk/140, query.h:822-823).  start_scale: first rmax = start_scale * config.rmax
+ * (<= 0: the reference's 8, query.h:862; every round is a whole cascade of levels on the GPU, so callers after
+ * throughput start at 1). */
+int fora_hip_set_balanced(fora_ctx *ctx, int on, double start_scale, double c_pop, double c_edge, double t_walk,
+                          double t_idx);
 /* queries processed concurrently per launch; 0 = choose from free HBM */
 int fora_hip_set_batch(fora_ctx *ctx, int batch);
 int fora_hip_get_batch(fora_ctx *ctx);

@@ -161,8 +161,8 @@ int orc_twin_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, cons
 /* --balanced (query.h:848-884) with the push charged by its work counters; returns the rounds run */
 int orc_twin_query_balanced(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax0,
                             double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
-                            const uint64_t *off, const uint64_t *cnt, double c_pop, double c_edge, double t_walk,
-                            double t_idx, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *pst,
+                            const uint64_t *off, const uint64_t *cnt, double start_scale, double c_pop, double c_edge,
+                            double t_walk, double t_idx, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *pst,
                             orc_refine_stats *rst, double *rmax_out);
 void orc_twin_bounds_node(double p, double reserve, double rsum, double L, double total, double min_ppr,
                           double sqrt_min_ppr, double *upper, double *lower);

@@ -515,14 +515,14 @@ int orc_twin_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, cons
  * the last rmax pushed with. */
 int orc_twin_query_balanced(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax0,
                             double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
-                            const uint64_t *off, const uint64_t *cnt, double c_pop, double c_edge, double t_walk,
-                            double t_idx, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *pst,
+                            const uint64_t *off, const uint64_t *cnt, double start_scale, double c_pop, double c_edge,
+                            double t_walk, double t_idx, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *pst,
                             orc_refine_stats *rst, double *rmax_out) {
     orc_twin_push_stats z = {0, 0, 0, 0};
     memset(residue, 0, sizeof(uint64_t) * (size_t)n);
     memset(ppr, 0, sizeof(uint64_t) * (size_t)n);
     int rounds = 0;
-    double rmax = rmax0 * 8; /* query.h:862 */
+    double rmax = rmax0 * (start_scale > 0 ? start_scale : 8); /* query.h:862 */
     if (row_ptr[s + 1] == row_ptr[s]) { /* :864, :882: plain push of a dangling source */
         ppr[s] = ORC_FIX_ONE;
         z.rsum_fix = 0;

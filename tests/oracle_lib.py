@@ -326,10 +326,10 @@ def calculate_lambda(rsum, pfail, upper_bound, total_rw_num):
 
 
 # MI355X cost model of --balanced (seconds): measured on the headline workload
-BAL_C_POP, BAL_C_EDGE, BAL_T_WALK, BAL_T_IDX = 1.0e-11, 1.2e-11, 6.5e-11, 2.2e-11
+BAL_C_POP, BAL_C_EDGE, BAL_T_WALK, BAL_T_IDX = 2.0e-11, 2.4e-11, 6.5e-11, 2.2e-11
 
 
-def twin_query_balanced(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None, c_pop=BAL_C_POP,
+def twin_query_balanced(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None, start_scale=0.0, c_pop=BAL_C_POP,
                         c_edge=BAL_C_EDGE, t_walk=BAL_T_WALK, t_idx=BAL_T_IDX):
     residue = np.zeros(g.n, dtype=np.uint64)
     ppr = np.zeros(g.n, dtype=np.uint64)
@@ -338,7 +338,7 @@ def twin_query_balanced(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=N
     a, b, c = _idx_args(index)
     f = lib().orc_twin_query_balanced
     rounds = f(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), C.c_int32(s), _d(rmax), _d(omega), _d(alpha),
-               C.c_int(int(opt)), C.c_uint64(seed), a, b, c, _d(c_pop), _d(c_edge), _d(t_walk), _d(t_idx),
+               C.c_int(int(opt)), C.c_uint64(seed), a, b, c, _d(start_scale), _d(c_pop), _d(c_edge), _d(t_walk), _d(t_idx),
                _p(residue), _p(ppr), C.byref(ps), C.byref(rs), C.byref(rm))
     return ppr, residue, dict(rsum_fix=ps.rsum_fix, levels=ps.levels, pops=ps.pops, relax=ps.relax,
                               n_walks=rs.n_walks, n_idx_hit=rs.n_idx_hit, rounds=rounds, rmax=rm.value)

@@ -416,6 +416,13 @@ def test_balanced_bit_exact_vs_twin(engine, oracle, small_dangling, with_idx):
             assert (np.abs(est - exact)[big] / exact[big]).max() <= 0.5
         else:
             assert st[i]["dangling_source"] == 1 and st[i]["rmax_used"] == rmax
+    # throughput flavour: first round at config.rmax
+    engine.set_balanced(True, start_scale=1.0)
+    p1, r1, s1 = engine.query_fix(srcs[:3], with_idx=with_idx)
+    engine.set_balanced(False)
+    for i, s in enumerate(srcs[:3]):
+        want, wres, wst = oracle.twin_query_balanced(g, int(s), rmax, omega, seed=SEED, index=index, start_scale=1.0)
+        assert (r1[i] == wres).all() and (p1[i] == want).all() and s1[i]["push_rounds"] == wst["rounds"]
     # plain mode reports one round at config.rmax
     _, _, st = engine.query_fix(srcs[:2])
     assert all(s["push_rounds"] == 1 and s["rmax_used"] == rmax for s in st)

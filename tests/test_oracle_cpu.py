@@ -297,3 +297,5 @@ def test_twin_balanced_mode(oracle, small):
             assert st["n_walks"] < st0["n_walks"] and st["relax"] > st0["relax"]
         _, _, free = oracle.twin_query_balanced(g, s, rmax, omega, seed=SEED, t_walk=1e-30)
         assert free["rounds"] == 1 and free["rmax"] == rmax * 8
+        _, _, one = oracle.twin_query_balanced(g, s, rmax, omega, seed=SEED, start_scale=1.0)
+        assert one["rmax"] == rmax / 2 ** (one["rounds"] - 1) and one["rounds"] < st["rounds"]
