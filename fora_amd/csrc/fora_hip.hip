@@ -271,7 +271,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         uint64_t budget = (uint64_t)(fr * 0.4); // a second lane may hold its own workspace
-        B = (int)std::min<uint64_t>(512, std::max<uint64_t>(1, budget / p.per_slot)); // ws: 2977 q/s at 512 vs 2845 at 256
+        B = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, budget / p.per_slot)); // ws, 1000 queries: 2845 q/s at 256, 3035 at 512, 3101 at 1000
     }
     B = std::max(1, B);
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));

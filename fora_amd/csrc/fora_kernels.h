@@ -1292,7 +1292,13 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
 // A wave collects (dest, weight) pairs in its own LDS area; when the area is nearly full it
 // bins them by target range (LDS counters), reserves bucket space with ONE global atomic per
 // (flush, bin), and stores them.  k_accum then reduces every (slot, bin) bucket in LDS.
-constexpr int STAGE = 256; // pairs per wave (512: 4 workgroups per CU by LDS; 256 + the register cap below: 5, 2-3 % faster)
+#ifndef FORA_STAGE
+#define FORA_STAGE 320
+#endif
+#ifndef FORA_WALK_WPE
+#define FORA_WALK_WPE 5
+#endif
+constexpr int STAGE = FORA_STAGE; // pairs per wave: the largest stage that still fits 5 workgroups per CU (with the register cap below); with the bin-sorted flush: 256 -> 558 ms, 320 -> 539, 384 -> 567-574, 512 -> 559 per 3000 ws queries
 struct WaveStage {
     uint32_t *dest;  // [STAGE]
     uint64_t *wgt;   // [STAGE]
@@ -1309,35 +1315,52 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
     uint32_t dst[STAGE / 64], rk[STAGE / 64];
+    uint64_t wv[STAGE / 64];
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++) {
         const uint32_t m = k * 64 + lane;
         dst[k] = 0xFFFFFFFFu;
         if (m < st.count) {
             dst[k] = st.dest[m];
+            wv[k] = st.wgt[m];
             rk[k] = atomicAdd(&st.bcnt[dst[k] >> BIN_SHIFT], 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
+    { // bucket space: ONE global atomic per (flush, bin); and the bins' offsets inside the wave's stage
+        const uint32_t c0 = lane < d.nbins ? st.bcnt[lane] : 0, c1 = lane + 64 < d.nbins ? st.bcnt[lane + 64] : 0;
+        uint32_t t0, t1;
+        const uint32_t o0 = wave_excl_scan(c0, t0), o1 = wave_excl_scan(c1, t1);
+        if (c0) st.bbase[lane] = atomicAdd(&bkc[lane * CSTRIDE], c0);
+        if (c1) st.bbase[lane + 64] = atomicAdd(&bkc[(lane + 64) * CSTRIDE], c1);
+        st.bcnt[lane] = o0;           // from here on: first stage slot of the bin
+        st.bcnt[lane + 64] = t0 + o1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // sort the stage by bin in place (every entry is in registers), so that consecutive lanes store to consecutive
+    // bucket slots: one write request per run instead of two per walk
 #pragma unroll
-    for (int h = 0; h < MAX_BINS; h += 64)
-        if (lane + h < d.nbins) {
-            const uint32_t c = st.bcnt[lane + h];
-            if (c) st.bbase[lane + h] = atomicAdd(&bkc[(lane + h) * CSTRIDE], c);
+    for (int k = 0; k < STAGE / 64; k++)
+        if (dst[k] != 0xFFFFFFFFu) {
+            const uint32_t sp = st.bcnt[dst[k] >> BIN_SHIFT] + rk[k];
+            st.dest[sp] = dst[k];
+            st.wgt[sp] = wv[k];
         }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++) {
-        if (dst[k] != 0xFFFFFFFFu) {
-            const uint32_t b = dst[k] >> BIN_SHIFT;
-            const uint32_t pos = st.bbase[b] + rk[k];
-            const uint64_t w = st.wgt[k * 64 + lane];
+        const uint32_t m = k * 64 + lane;
+        if (m < st.count) {
+            const uint32_t dd = st.dest[m];
+            const uint64_t w = st.wgt[m];
+            const uint32_t b = dd >> BIN_SHIFT;
+            const uint32_t pos = st.bbase[b] + (m - st.bcnt[b]);
             if (pos < d.bk_cap) {
                 const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
-                d.bk_w[at] = dst[k];
+                d.bk_w[at] = dd;
                 d.bk_inc[at] = w;
             } else { // bucket full: direct atomic, same sum
-                atomicAdd((unsigned long long *)&d.ppr[slab + dst[k]], (unsigned long long)w);
+                atomicAdd((unsigned long long *)&d.ppr[slab + dd], (unsigned long long)w);
             }
         }
     }
@@ -1504,7 +1527,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
 // for the longest walk of the wave.  Walks start on even iterations only, hence all running
 // walks of a wave share step parity and the Philox call (one per two steps) is wave-uniform.
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_walk_online(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA_WALK_WPE, 8))) k_walk_online(Dev d, uint32_t round, int nzh, int32_t *idx_out) {
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
     const int q = blockIdx.y;
