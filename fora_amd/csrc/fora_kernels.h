@@ -503,8 +503,9 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     __shared__ uint32_t s_pref[BLOCK + 1];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[BLOCK * BIN_EPT];
-    __shared__ uint32_t s_sidx[WIDE ? BLOCK * BIN_EPT : 1]; // wide: source of each staged message (its increment)
+    // stage: narrow = message + bucket slot; wide = ONE word per message, local target (13 bits) | source node inside
+    // the tile (8) | bin (10) -- 8 KiB instead of 24, which lifts the wide kernel from 3 to 5 workgroups per CU
+    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[WIDE ? 1 : BLOCK * BIN_EPT];
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t *in = d.fl[par] + slab;
@@ -629,26 +630,43 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
             for (int k = 0; k < BIN_EPT; k++) {
                 if (w[k] != 0xFFFFFFFFu) {
                     const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
-                    const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    if (WIDE) { s_msg[sp] = w[k] & (BIN_SIZE - 1); s_sidx[sp] = si[k]; }
-                    else s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
-                    s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
-                    if (pos >= d.bk_cap) { // bucket full: park the increment in the slot's overflow list
-                        const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
-                        if (oi < d.ov_cap) {
-                            d.ov_w[(uint64_t)q * d.ov_cap + oi] = w[k];
-                            d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[si[k]];
-                        } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
+                    if (WIDE) {
+                        s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (si[k] << BIN_SHIFT) | (b << (BIN_SHIFT + 8));
+                    } else {
+                        const uint32_t pos = s_base[b] + rank[k];
+                        s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
+                        s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
+                        if (pos >= d.bk_cap) { // bucket full: park the increment in the slot's overflow list
+                            const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
+                            if (oi < d.ov_cap) {
+                                d.ov_w[(uint64_t)q * d.ov_cap + oi] = w[k];
+                                d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[si[k]];
+                            } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
+                        }
                     }
                 }
             }
             __syncthreads();
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
-                const uint32_t dst = s_dst[m];
-                if (dst != 0xFFFFFFFFu) {
-                    d.bk_w[bk0 + dst] = s_msg[m];
-                    if (WIDE) d.bk_inc[bk0 + dst] = s_inc[s_sidx[m]];
+                if (WIDE) {
+                    const uint32_t e = s_msg[m];
+                    const uint32_t b = e >> (BIN_SHIFT + 8), sidx = (e >> BIN_SHIFT) & 255u, local = e & (BIN_SIZE - 1);
+                    const uint32_t pos = s_base[b] + (m - s_lofs[b]);
+                    if (pos < d.bk_cap) {
+                        const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
+                        d.bk_w[at] = local;
+                        d.bk_inc[at] = s_inc[sidx];
+                    } else { // bucket full: park the increment in the slot's overflow list
+                        const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
+                        if (oi < d.ov_cap) {
+                            d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
+                            d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
+                        } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
+                    }
+                } else {
+                    const uint32_t dst = s_dst[m];
+                    if (dst != 0xFFFFFFFFu) d.bk_w[bk0 + dst] = s_msg[m];
                 }
             }
         }
