@@ -23,6 +23,7 @@ static const char *const TOPK = "topk";
 static const char *const BUILD = "build";
 static const char *const GEN_EXACT_TOPK = "gen-exact-topk"; // config.h:37
 static const char *const CHECK_GRAPH = "check-graph"; // not in the reference: loader self-check
+static const char *const CHECK_INDEX = "check-index"; // not in the reference: index file self-check (no GPU needed)
 static const char *const FORA = "fora";
 
 // timer slots: config.h:47-57
@@ -52,6 +53,7 @@ struct Config { // config.h:86-160
     uint64_t seed = 0x464F5241ull;
     int device = 0;
     int batch = 0;
+    bool boost_idx = false;    // build --boost_idx: write the index as Boost binary archives (presumed 1.65 layout)
     double balanced_start = 0; // --balanced_start S: first rmax of --balanced = S * rmax (0: the reference's 8)
     int gpus = 1;   // --gpus N: sources i mod N on GPU (device + i mod N), one host thread per GPU
     std::string get_graph_folder() const { return prefix + graph_alias + "/"; } // config.h:99-101

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -91,9 +92,10 @@ struct Graph {
 };
 
 // ---- walk index files ---------------------------------------------------------------
-// Names follow build.h:147-181.  The reference writes Boost binary_oarchive streams, which
-// cannot be produced or checked here (no Boost); this is a native container with the same
-// two arrays (rw_idx, rw_idx_info) -- interop with Boost files is SURVEY.md 8f rank 1.
+// Names follow build.h:147-181.  Default container: a native one with the reference's two arrays
+// (rw_idx, rw_idx_info).  The reference's own files are Boost binary_oarchive streams: they are
+// READ when found (tail-anchored parse, see below) and can be written with `build --boost_idx`;
+// both in a layout stated from the Boost sources' documented behaviour, unpinned (no Boost here).
 struct IndexFile {
     static constexpr uint64_t MAGIC = 0x31584449414F46ull; // "FOAIDX1"
     static std::string base(const std::string &loc, double rmax_scale, bool opt, const char *kind) {
@@ -117,6 +119,86 @@ struct IndexFile {
         fclose(a); fclose(b);
         return true;
     }
+    // ---- Boost binary_oarchive files of the reference (serialize_idx / deserialize_idx, build.h:194-217) ----------
+    // Layout as far as it can be stated without Boost at hand (UNPINNED: no reference-written file was available):
+    //   u64 22, "serialization::archive", u16 library version, u8 sizeof(int,long,float,double), u32 1   (40 bytes)
+    //   randwalks.idx : vector<int>                -> u64 count, count raw int32                (array optimisation)
+    //   randwalks.info: vector<pair<ull, ulong>>   -> class preamble (class id i16, tracking u8, version u32),
+    //                                                 u64 count, count raw 16-byte pairs        (bitwise serializable)
+    // The READER does not depend on the preamble: it checks the signature, takes the payload from the END of the file
+    // (16 n bytes / 4 * sum(cnt) bytes) and requires the u64 in front of it to be the element count.
+    static constexpr const char *BOOST_SIG = "serialization::archive";
+    static bool boost_header_ok(const std::vector<unsigned char> &f) {
+        if (f.size() < 40) return false;
+        uint64_t len;
+        memcpy(&len, f.data(), 8);
+        return len == 22 && memcmp(f.data() + 8, BOOST_SIG, 22) == 0;
+    }
+    static bool slurp(const std::string &path, std::vector<unsigned char> &out) {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        out.resize((size_t)sz);
+        const bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+        fclose(f);
+        return ok;
+    }
+    static bool read_boost(const std::string &fa, const std::string &fb, int32_t n, std::vector<int32_t> &rw,
+                           std::vector<uint64_t> &off, std::vector<uint64_t> &cnt, std::string &err) {
+        std::vector<unsigned char> info, idx;
+        if (!slurp(fb, info) || !boost_header_ok(info)) return false;
+        const size_t pay = (size_t)n * 16;
+        uint64_t c = 0;
+        if (info.size() < 40 + 8 + pay) { err = fb + ": Boost archive too short for n pairs"; return false; }
+        memcpy(&c, info.data() + info.size() - pay - 8, 8);
+        if (c != (uint64_t)n) { err = fb + ": Boost archive whose element count is not n"; return false; }
+        off.resize((size_t)n); cnt.resize((size_t)n);
+        uint64_t total = 0;
+        for (int32_t v = 0; v < n; v++) {
+            uint64_t p[2];
+            memcpy(p, info.data() + info.size() - pay + (size_t)v * 16, 16);
+            off[v] = p[0]; cnt[v] = p[1];
+            if (p[0] != total) { err = fb + ": offsets are not the running sum of the counts (build.h:331-333)"; return false; }
+            total += p[1];
+        }
+        if (!slurp(fa, idx) || !boost_header_ok(idx)) { err = fa + ": not a Boost binary archive"; return false; }
+        if (idx.size() < 40 + 8 + total * 4) { err = fa + ": Boost archive too short for the walks of its .info"; return false; }
+        memcpy(&c, idx.data() + idx.size() - total * 4 - 8, 8);
+        if (c != total) { err = fa + ": element count does not match its .info"; return false; }
+        rw.resize(total);
+        if (total) memcpy(rw.data(), idx.data() + idx.size() - total * 4, total * 4);
+        for (uint64_t i = 0; i < total; i++)
+            if (rw[i] < 0 || rw[i] >= n) { err = fa + ": walk endpoint out of range"; return false; }
+        return true;
+    }
+    // Writer in the same presumed layout (`fora build --boost_idx`); library version 15 = Boost 1.64-1.65 (README.md:46)
+    static bool write_boost(const std::string &loc, double rmax_scale, bool opt, int32_t n, const std::vector<int32_t> &rw,
+                            const std::vector<uint64_t> &off, const std::vector<uint64_t> &cnt, std::string &err) {
+        FILE *a = fopen(base(loc, rmax_scale, opt, "idx").c_str(), "wb");
+        FILE *b = fopen(base(loc, rmax_scale, opt, "info").c_str(), "wb");
+        if (!a || !b) { err = "cannot write index files in " + loc; if (a) fclose(a); if (b) fclose(b); return false; }
+        auto header = [](FILE *f) {
+            const uint64_t len = 22;
+            const uint16_t ver = 15;
+            const unsigned char sizes[4] = {4, 8, 4, 8};
+            const uint32_t one = 1;
+            fwrite(&len, 8, 1, f); fwrite(BOOST_SIG, 1, 22, f); fwrite(&ver, 2, 1, f); fwrite(sizes, 1, 4, f); fwrite(&one, 4, 1, f);
+        };
+        header(a);
+        const uint64_t na = rw.size();
+        fwrite(&na, 8, 1, a);
+        fwrite(rw.data(), 4, rw.size(), a);
+        header(b);
+        const int16_t class_id = 0; const unsigned char tracking = 0; const uint32_t version = 0;
+        fwrite(&class_id, 2, 1, b); fwrite(&tracking, 1, 1, b); fwrite(&version, 4, 1, b);
+        const uint64_t nb = (uint64_t)n;
+        fwrite(&nb, 8, 1, b);
+        for (int32_t v = 0; v < n; v++) { uint64_t p[2] = {off[v], cnt[v]}; fwrite(p, 8, 2, b); }
+        fclose(a); fclose(b);
+        return true;
+    }
     static bool read(const std::string &loc, double rmax_scale, bool opt, int32_t n, std::vector<int32_t> &rw,
                      std::vector<uint64_t> &off, std::vector<uint64_t> &cnt, std::string &err) {
         const std::string fa = base(loc, rmax_scale, opt, "idx"), fb = base(loc, rmax_scale, opt, "info");
@@ -133,7 +215,11 @@ struct IndexFile {
             for (int32_t v = 0; ok && v < n; v++) { uint64_t p[2]; ok = fread(p, 8, 2, b) == 2; off[v] = p[0]; cnt[v] = p[1]; }
         }
         fclose(a); fclose(b);
-        if (!ok) err = "index files are not in this build's format (Boost archives are not supported)";
+        if (!ok) { // not this build's container: a Boost archive written by the reference?
+            std::string berr;
+            if (read_boost(fa, fb, n, rw, off, cnt, berr)) return true;
+            err = berr.empty() ? "index files are neither this build's container nor a Boost binary archive" : berr;
+        }
         return ok;
     }
 };

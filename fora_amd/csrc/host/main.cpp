@@ -432,7 +432,9 @@ static int do_build(Graph &graph) { // build(), build.h:302-366
     rw.resize(total);
     info("rw_idx.size()", rw.size());
     string err;
-    if (!IndexFile::write(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)) {
+    const bool wrote = config.boost_idx ? IndexFile::write_boost(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)
+                                        : IndexFile::write(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err);
+    if (!wrote) {
         cerr << err << endl;
         fora_hip_destroy(ctx);
         return 1;
@@ -473,6 +475,7 @@ int main(int argc, char *argv[]) {
         else if (arg == "--dataset") config.graph_alias = next("--dataset");
         else if (arg == "--opt") config.opt = true;
         else if (arg == "--balanced") config.balanced = true;
+        else if (arg == "--boost_idx") config.boost_idx = true;
         else if (arg == "--balanced_start") config.balanced_start = atof(next("--balanced_start"));
         else if (arg == "--seed") config.seed = strtoull(next("--seed"), nullptr, 0);
         else if (arg == "--device") config.device = atoi(next("--device"));
@@ -484,7 +487,8 @@ int main(int argc, char *argv[]) {
     info("config.action", config.action);
 
     const string act = config.action;
-    if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH && act != GEN_EXACT_TOPK) {
+    if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH && act != GEN_EXACT_TOPK &&
+        act != CHECK_INDEX) {
         cerr << "sub command not regoznized" << endl; // fora.cpp:278-281
         return 1;
     }
@@ -497,7 +501,7 @@ int main(int argc, char *argv[]) {
     config.graph_location = config.get_graph_folder();
     Graph graph;
     graph.data_folder = config.graph_location;
-    const bool ok = act == GEN_SS_QUERY ? graph.init_nm() : graph.init_graph(); // graph.h:40-43
+    const bool ok = (act == GEN_SS_QUERY || act == CHECK_INDEX) ? graph.init_nm() : graph.init_graph(); // graph.h:40-43
     if (!ok) { cerr << graph.error << endl; return 1; }
     cout << "init graph n: " << graph.n << " m: " << graph.m << endl;
     config.delta = 1.0 / graph.n; // init_parameter, graph.h:173-183
@@ -511,6 +515,19 @@ int main(int argc, char *argv[]) {
         if (config.exact_pprs_folder.empty() || stat(config.exact_pprs_folder.c_str(), &sb) != 0) config.exact_pprs_folder = config.graph_location;
     }
     int rc = 0;
+    if (act == CHECK_INDEX) { // reads randwalks.idx/.info (this build's container or a Boost archive of the reference)
+        IndexData ix;
+        string err;
+        if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, ix.rw, ix.off, ix.cnt, err)) {
+            cerr << err << endl;
+            return 1;
+        }
+        uint64_t h = 1469598103934665603ull;
+        for (int32_t v : ix.rw) { h ^= (uint32_t)v; h *= 1099511628211ull; }
+        for (size_t v = 0; v < ix.cnt.size(); v++) { h ^= ix.off[v]; h *= 1099511628211ull; h ^= ix.cnt[v]; h *= 1099511628211ull; }
+        cout << "index walks: " << ix.rw.size() << " nodes: " << ix.cnt.size() << " fnv1a: " << h << endl;
+        return 0;
+    }
     if (act == CHECK_GRAPH) {
         uint64_t h = 1469598103934665603ull;
         for (int32_t c : graph.col) { h ^= (uint32_t)c; h *= 1099511628211ull; }

@@ -116,6 +116,14 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
         walks = sum(oracle.twin_query(g, int(s), rmax, omega, seed=0x464F5241)[2]["n_walks"] for s in queries[:10])
         assert float(j["result"]["total number of rand-walks"]) == walks
         assert set(j["timer"]) >= {"3", "5", "6"}
+    # the same index as Boost binary archives (build --boost_idx): same content, read back by query --with_idx
+    h_native = _run([cli, "check-index", *common]).stdout.strip().split("\n")[-1]
+    r = _run([cli, "build", "--boost_idx", *common])
+    assert r.returncode == 0, r.stderr
+    assert open(folder / "randwalks.idx", "rb").read(30)[8:] == b"serialization::archive"
+    assert _run([cli, "check-index", *common]).stdout.strip().split("\n")[-1] == h_native
+    r = _run([cli, "query", "--algo", "fora", "--query_size", "3", "--with_idx", *common])
+    assert r.returncode == 0 and "Average rand-walk idx hit ratio: 100%" in r.stdout
     # --balanced (README.md:135 "TODS version"): adaptive rmax, same outputs; walk total equals the twin's
     r = _run([cli, "query", "--algo", "fora", "--balanced", "--query_size", "4", "--result_dir", str(tmp_path / "resb"), *common[:6]])
     assert r.returncode == 0, r.stderr
@@ -210,3 +218,50 @@ def test_cli_gen_exact_topk_and_precision(cli, oracle, small, tmp_path):
     assert abs(float(j["result"]["topk precision"]) - prec / 4) < 1e-12
     assert abs(float(j["result"]["topk recall"]) - rec / 4) < 1e-12
     assert float(j["result"]["topk precision"]) >= 0.8
+
+
+def _fnv(rw, off, cnt):
+    h = 1469598103934665603
+    M = (1 << 64) - 1
+    for v in rw:
+        h = ((h ^ (int(v) & 0xFFFFFFFF)) * 1099511628211) & M
+    for o, c in zip(off, cnt):
+        h = ((h ^ int(o)) * 1099511628211) & M
+        h = ((h ^ int(c)) * 1099511628211) & M
+    return h
+
+
+def test_index_files_boost_archive_reader(cli, tmp_path):
+    """deserialize_idx (build.h:194-207) reads Boost binary archives.  No Boost here, so the layout is the presumed one
+    (unpinned); the reader anchors on the signature, the payload at the END of the file and the count in front of it,
+    so extra preamble bytes (class info, item version) do not matter.  `fora check-index` needs no GPU."""
+    import struct
+    n = 50
+    rng = np.random.Generator(np.random.PCG64(5))
+    cnt = rng.integers(0, 7, size=n).astype(np.uint64)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.uint64)
+    rw = rng.integers(0, n, size=int(cnt.sum())).astype(np.int32)
+    folder = tmp_path / "data" / "g"
+    os.makedirs(folder)
+    open(folder / "attribute.txt", "w").write(f"n={n}\nm=100\n")
+    header = struct.pack("<Q", 22) + b"serialization::archive" + struct.pack("<H", 15) + bytes([4, 8, 4, 8]) + struct.pack("<I", 1)
+    pairs = b"".join(struct.pack("<QQ", int(o), int(c)) for o, c in zip(off, cnt))
+    want = f"index walks: {rw.size} nodes: {n} fnv1a: {_fnv(rw, off, cnt)}"
+    common = ["--prefix", str(tmp_path / "data") + "/", "--dataset", "g"]
+    for preamble in (struct.pack("<hBI", 0, 0, 0), b"", struct.pack("<hBIxxxx", 0, 0, 0)):
+        open(folder / "randwalks.idx", "wb").write(header + struct.pack("<Q", rw.size) + rw.tobytes())
+        open(folder / "randwalks.info", "wb").write(header + preamble + struct.pack("<Q", n) + pairs)
+        r = _run([cli, "check-index", *common])
+        assert r.returncode == 0, r.stderr
+        assert want in r.stdout
+    # corrupt count / truncated payload / foreign file are refused with a reason
+    open(folder / "randwalks.info", "wb").write(header + struct.pack("<Q", n + 1) + pairs)
+    r = _run([cli, "check-index", *common])
+    assert r.returncode == 1 and "element count" in r.stderr
+    open(folder / "randwalks.info", "wb").write(header + struct.pack("<Q", n) + pairs)
+    open(folder / "randwalks.idx", "wb").write(header + struct.pack("<Q", rw.size) + rw.tobytes()[:-4])
+    r = _run([cli, "check-index", *common])
+    assert r.returncode == 1
+    open(folder / "randwalks.idx", "wb").write(b"not an archive at all, just bytes " * 4)
+    r = _run([cli, "check-index", *common])
+    assert r.returncode == 1
