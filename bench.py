@@ -271,9 +271,9 @@ def main():
                 "walks_per_query": float(np.mean([s["n_walks"] for s in stb])),
                 "start_scale": args.balanced_start,
                 "note": "--balanced (query.h:848-884) with the MI355X cost model of fora_hip_set_balanced; same guarantee"}}
-        # roofline of the dominant push kernel (k_push_expand): ALGORITHMIC bytes = 24 B per edge
-        # relaxation of the sequential FIFO oracle; relaxations the level-synchronous
-        # schedule adds on top are not credited.  Duration: HIP events around every launch.
+        # roofline of the push kernels: ALGORITHMIC bytes = 52 B per pop + 24 B per edge relaxation of the
+        # sequential FIFO oracle; relaxations the level-synchronous schedule adds on top are
+        # not credited.  Duration: HIP events around every launch.
         if tm["push_expand_launches"]:
             e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
             p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)

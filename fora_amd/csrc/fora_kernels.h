@@ -35,7 +35,7 @@ constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 ac
 constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
 constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-B push messages (target, increment)
 constexpr int ACC_THREADS = 512;
-constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin
+constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_popbin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
 
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(BLOCK) k_push_pop(Dev d, int L) {
 }
 
 // ------------------------------------------------------------------ push: expand
-// The roofline kernel.  A block stages 256 edge slices in LDS (first edge, increment,
+// Direct (one atomic per edge) form, FORA_HIP_DIRECT=1 only.  A block stages 256 edge slices in LDS (first edge, increment,
 // slot, prefix sum of slice lengths), then its threads walk the concatenated edge
 // range: consecutive threads read consecutive col entries (coalesced), add the
 // increment to residue[q][w] with one returning u64 atomic, and the thread whose
@@ -469,14 +469,13 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // ------------------------------------------------------------------ bucketed push
 // Same level semantics as k_push_pop / k_push_expand, reorganised so that no per-edge global
 // atomic is needed (measured: every global atomic flavour caps at ~23 G/s chip-wide, ~5 G/s
-// with power-law hot targets).  Per level:
-//   k_pushq_pop    frontier (per-slot list) -> reserve + <=256-edge slices (per-slot list)
-//   k_pushq_bin    slices -> increments binned by target range: per 2048-edge chunk an LDS
-//                  histogram, ONE global atomic per (chunk, bin) to reserve bucket space,
-//                  then coalesced-by-bin message stores
-//   k_pushq_accum  one workgroup per (slot, bin): ds_add_u64 every message into 64 KiB of LDS
-//                  accumulators, then sweep them: one plain RMW per touched node (the
-//                  workgroup owns that residue range), threshold crossing -> next frontier
+// with power-law hot targets).  Per level (and per pass of <= 1024 bins on huge graphs):
+//   k_pushq_popbin  frontier (per-slot list) -> reserve, increments binned by target range: per
+//                   2048-edge chunk an LDS histogram, ONE global atomic per (chunk, bin) to
+//                   reserve bucket space, then bin-sorted message stores
+//   k_accum<false>  one workgroup per (slot, bin): ds_add_u64 every message into 64 KiB of LDS
+//                   accumulators, then sweep them: one plain RMW per touched node (the
+//                   workgroup owns that residue range), threshold crossing -> next frontier
 // Integer adds commute, so the result is bit-identical to the direct path and to the twin.
 
 // grid = (X, nq).  Fused pop + bin: a block takes 256 frontier nodes of a slot, pops them (residue ->

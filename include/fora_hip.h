@@ -55,9 +55,9 @@ typedef struct {
 
 /* Accumulated device timings since the last reset (HIP events on the ctx stream). */
 typedef struct {
-    double push_pop_ms;     /* sum over k_push_pop launches */
-    double push_expand_ms;  /* sum over k_push_expand / k_pushq_bin launches */
-    double push_accum_ms;   /* sum over k_pushq_accum launches (bucketed push only) */
+    double push_pop_ms;     /* sum over k_push_pop launches (direct path only) */
+    double push_expand_ms;  /* sum over k_pushq_popbin launches (k_push_expand on the direct path) */
+    double push_accum_ms;   /* sum over k_accum<false> launches (bucketed push only) */
     double walk_alloc_ms;   /* k_walk_alloc */
     double walk_ms;         /* k_walk_idx + k_walk_online */
     double walk_accum_ms;   /* k_accum<to ppr> (bucketed path only) */
