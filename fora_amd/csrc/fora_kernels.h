@@ -38,6 +38,10 @@ constexpr int ACC_THREADS = 512;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_popbin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
+// Narrow layout: a walk result travels as ONE 64-bit word, node id (< 2^20) | weight << 20 (weights are r / num_s_rw,
+// about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
+constexpr int WPACK_SHIFT = 20;
+constexpr uint64_t WPACK_MAXW = 1ull << (64 - WPACK_SHIFT);
 
 // error flag bits (Dev::err)
 constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4, ERR_BUCKET_OVERFLOW = 8;
@@ -719,8 +723,13 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
             uint32_t w = 0;
             uint64_t inc = 0;
             if (i < cnt) {
-                w = d.bk_w[bk0 + i];
-                if (TO_PPR) inc = d.bk_inc[bk0 + i];
+                if (TO_PPR && !d.wide) { // narrow walk results: one packed word, node id | weight << WPACK_SHIFT
+                    const uint64_t pk = d.bk_inc[bk0 + i];
+                    w = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
+                    inc = pk >> WPACK_SHIFT;
+                } else w = d.bk_w[bk0 + i];
+                if (TO_PPR && d.wide) inc = d.bk_inc[bk0 + i];
+                else if (TO_PPR) {}
                 else if (d.wide) { inc = d.bk_inc[bk0 + i]; w = node0 + w; }
                 else {
                     inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
@@ -747,13 +756,14 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     constexpr int ACC_UNROLL = 8;
     const bool gather = !TO_PPR && !d.wide;
     const uint64_t *itab = d.inc_tab + (uint64_t)q * d.segq_cap;
+    const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
     for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
         uint32_t mw[ACC_UNROLL];
         uint64_t mi[ACC_UNROLL];
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mw[k] = d.bk_w[bk0 + (i < cnt ? i : 0)];
+            mw[k] = packed ? 0u : d.bk_w[bk0 + (i < cnt ? i : 0)];
         }
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
@@ -763,8 +773,10 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            const uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
-            if (i < cnt && mi[k]) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)mi[k]);
+            uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
+            uint64_t inc = mi[k];
+            if (packed) { local = (uint32_t)inc; inc >>= WPACK_SHIFT; }
+            if (i < cnt && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
         }
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
@@ -1310,15 +1322,14 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
 // bins them by target range (LDS counters), reserves bucket space with ONE global atomic per
 // (flush, bin), and stores them.  k_accum then reduces every (slot, bin) bucket in LDS.
 #ifndef FORA_STAGE
-#define FORA_STAGE 320
+#define FORA_STAGE 448
 #endif
 #ifndef FORA_WALK_WPE
 #define FORA_WALK_WPE 5
 #endif
-constexpr int STAGE = FORA_STAGE; // pairs per wave: the largest stage that still fits 5 workgroups per CU (with the register cap below); with the bin-sorted flush: 256 -> 558 ms, 320 -> 539, 384 -> 567-574, 512 -> 559 per 3000 ws queries
+constexpr int STAGE = FORA_STAGE; // results per wave: the largest stage that still fits 5 workgroups per CU (8-byte packed results, register cap below); 320 -> 520 ms, 448 -> 508, 480 -> 508 per 3000 ws queries
 struct WaveStage {
-    uint32_t *dest;  // [STAGE]
-    uint64_t *wgt;   // [STAGE]
+    uint64_t *pk;    // [STAGE]
     uint32_t *bcnt;  // [MAX_BINS]
     uint32_t *bbase; // [MAX_BINS]
     uint32_t count;  // wave-uniform
@@ -1331,16 +1342,16 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     st.bcnt[lane] = 0;
     st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
-    uint32_t dst[STAGE / 64], rk[STAGE / 64];
+    constexpr uint64_t NONE = ~0ull;
+    uint32_t rk[STAGE / 64];
     uint64_t wv[STAGE / 64];
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++) {
         const uint32_t m = k * 64 + lane;
-        dst[k] = 0xFFFFFFFFu;
+        wv[k] = NONE;
         if (m < st.count) {
-            dst[k] = st.dest[m];
-            wv[k] = st.wgt[m];
-            rk[k] = atomicAdd(&st.bcnt[dst[k] >> BIN_SHIFT], 1u);
+            wv[k] = st.pk[m];
+            rk[k] = atomicAdd(&st.bcnt[((uint32_t)wv[k] & ((1u << WPACK_SHIFT) - 1)) >> BIN_SHIFT], 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1355,52 +1366,45 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     }
     __builtin_amdgcn_wave_barrier();
     // sort the stage by bin in place (every entry is in registers), so that consecutive lanes store to consecutive
-    // bucket slots: one write request per run instead of two per walk
+    // bucket slots: one write request per run instead of one per walk
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++)
-        if (dst[k] != 0xFFFFFFFFu) {
-            const uint32_t sp = st.bcnt[dst[k] >> BIN_SHIFT] + rk[k];
-            st.dest[sp] = dst[k];
-            st.wgt[sp] = wv[k];
-        }
+        if (wv[k] != NONE) st.pk[st.bcnt[((uint32_t)wv[k] & ((1u << WPACK_SHIFT) - 1)) >> BIN_SHIFT] + rk[k]] = wv[k];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < STAGE / 64; k++) {
         const uint32_t m = k * 64 + lane;
         if (m < st.count) {
-            const uint32_t dd = st.dest[m];
-            const uint64_t w = st.wgt[m];
+            const uint64_t pk = st.pk[m];
+            const uint32_t dd = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
             const uint32_t b = dd >> BIN_SHIFT;
             const uint32_t pos = st.bbase[b] + (m - st.bcnt[b]);
-            if (pos < d.bk_cap) {
-                const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
-                d.bk_w[at] = dd;
-                d.bk_inc[at] = w;
-            } else { // bucket full: direct atomic, same sum
-                atomicAdd((unsigned long long *)&d.ppr[slab + dd], (unsigned long long)w);
-            }
+            if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * d.bk_cap + pos] = pk;
+            else atomicAdd((unsigned long long *)&d.ppr[slab + dd], (unsigned long long)(pk >> WPACK_SHIFT)); // bucket full
         }
     }
     __builtin_amdgcn_wave_barrier();
     st.count = 0;
 }
 __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, bool has, uint32_t dest, uint64_t w) {
+    if (has && w >= WPACK_MAXW) { // does not fit the packed word (tiny walk budgets only)
+        atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + dest], (unsigned long long)w);
+        has = false;
+    }
     const unsigned long long mask = __ballot(has);
     if (!mask) return;
     if (has) {
         const uint32_t pos = st.count + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1));
-        st.dest[pos] = dest;
-        st.wgt[pos] = w;
+        st.pk[pos] = (uint64_t)dest | (w << WPACK_SHIFT);
     }
     st.count += (uint32_t)__popcll(mask);
     if (st.count > STAGE - 64) stage_flush(d, q, st);
 }
 #define WAVE_STAGE_DECL(st)                                                                         \
-    __shared__ uint32_t st##_dest[BLOCK / 64][STAGE];                                               \
-    __shared__ uint64_t st##_wgt[BLOCK / 64][STAGE];                                                \
+    __shared__ uint64_t st##_pk[BLOCK / 64][STAGE];                                                 \
     __shared__ uint32_t st##_bcnt[BLOCK / 64][MAX_BINS], st##_bbase[BLOCK / 64][MAX_BINS];         \
     WaveStage st;                                                                                   \
-    st.dest = st##_dest[threadIdx.x >> 6]; st.wgt = st##_wgt[threadIdx.x >> 6];                     \
+    st.pk = st##_pk[threadIdx.x >> 6];                                                              \
     st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6]; st.count = 0;
 
 // ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
@@ -1413,9 +1417,10 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_pref[BLOCK + 1], s_w[4];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    __shared__ uint32_t s_msg[NB > 1 ? BLOCK * EPT : 1], s_dst[NB > 1 ? BLOCK * EPT : 1];
-    __shared__ uint64_t s_val[NB > 1 ? BLOCK * EPT : 1];
     constexpr bool BINNED = NB > 1;
+    constexpr bool PACK = BINNED && NB <= MAX_BINS; // narrow: one word per result, node id | weight << WPACK_SHIFT
+    __shared__ uint32_t s_msg[BINNED && !PACK ? BLOCK * EPT : 1], s_dst[NB > 1 ? BLOCK * EPT : 1];
+    __shared__ uint64_t s_val[NB > 1 ? BLOCK * EPT : 1];
     const int q = blockIdx.y;
     const uint32_t nitems = d.wit_count[q * CSTRIDE];
     if (!nitems) return;
@@ -1478,6 +1483,14 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                         atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
                 continue;
             }
+            if (PACK) {
+#pragma unroll
+                for (int k = 0; k < EPT; k++)
+                    if (dest[k] != 0xFFFFFFFFu && wgt[k] >= WPACK_MAXW) { // does not fit the packed word
+                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
+                        dest[k] = 0xFFFFFFFFu;
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 if (dest[k] != 0xFFFFFFFFu && (dest[k] >> BIN_SHIFT) - bin_lo >= bin_cnt) dest[k] = 0xFFFFFFFFu; // another pass
@@ -1517,8 +1530,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                     const uint32_t b = (dest[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    s_msg[sp] = dest[k];
-                    s_val[sp] = wgt[k];
+                    if (PACK) s_val[sp] = (uint64_t)dest[k] | (wgt[k] << WPACK_SHIFT);
+                    else { s_msg[sp] = dest[k]; s_val[sp] = wgt[k]; }
                     s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
                     if (pos >= d.bk_cap) // bucket full: direct atomic, same sum
                         atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
@@ -1528,7 +1541,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) {
                 const uint32_t dst = s_dst[m];
                 if (dst != 0xFFFFFFFFu) {
-                    d.bk_w[bk0 + dst] = s_msg[m];
+                    if (!PACK) d.bk_w[bk0 + dst] = s_msg[m];
                     d.bk_inc[bk0 + dst] = s_val[m];
                 }
             }
