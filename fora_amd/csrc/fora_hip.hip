@@ -417,6 +417,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     const int nq = d.nq;
     unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
     if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
+    uint32_t tail_max = 1024; // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
+    if (const char *e = getenv("FORA_HIP_TAIL")) tail_max = (uint32_t)std::max(0, atoi(e));
+    const char *ta = getenv("FORA_HIP_TAIL_ALWAYS"); // tests: do not wait for the frontier to have been large first
+    bool past_peak = ta && ta[0] == '1';
     for (;; L++) {
         if (level_cap > 0 && L >= level_cap) break; // power iteration: a fixed number of levels
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
@@ -452,12 +456,27 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
             const int K = L - SPEC;
             if (hipEventSynchronize(done[K % (SPEC + 1)]) != hipSuccess) { rc = fail(c, FORA_E_HIP, "event sync"); break; }
             bool empty;
+            uint32_t fmax = 0;
             if (c->binned) {
                 empty = true;
                 const uint32_t *cnt = c->h_flc + (size_t)((K + 1) % FLC_RING) * c->B * CSTRIDE;
-                for (int i = 0; i < nq && empty; i++) empty = cnt[(size_t)i * CSTRIDE] == 0;
+                for (int i = 0; i < nq; i++) { fmax = std::max(fmax, cnt[(size_t)i * CSTRIDE]); }
+                empty = fmax == 0;
             } else {
                 empty = c->h_pinned[K + 1] == 0;
+            }
+            if (fmax > tail_max) past_peak = true; // the first levels are small too, but growing
+            if (!empty && c->binned && tail_max > 0 && past_peak && fmax <= tail_max) {
+                // every slot's frontier is small: finish inside one workgroup per slot instead of launching levels
+                const int next = L + 1;
+                const int remaining = level_cap > 0 ? level_cap - next : 0;
+                if (level_cap <= 0 || remaining > 0) {
+                    int h = ev_begin(c, 1);
+                    hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, d, next, remaining);
+                    ev_end(c, h);
+                    c->timing.levels++;
+                }
+                break;
             }
             if (empty) break;
         }

@@ -687,6 +687,137 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     }
 }
 
+// ---- tail of the push.  Once every slot's frontier is small the per-level launches are pure latency (two launches of
+// ~10-20 us each plus their gaps, for a few hundred relaxations per slot).  This kernel finishes the push of a slot
+// inside ONE workgroup: the same level-synchronous schedule -- all pops of a level, then its relaxations, then the
+// dangling mass -- with workgroup barriers instead of launches and one returning atomic per relaxation (the slot's
+// slabs are touched by this workgroup only; every mutable word is read and written through atomics or cache-bypassing
+// loads, so no stale L1 line is ever observed).  Integer adds commute: same bits as the bucketed levels and the twin.
+// grid = nq, TAIL_THREADS threads.  L0: first level to run; max_levels: stop after that many more (0: until empty).
+constexpr int TAIL_THREADS = 1024;
+__global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int max_levels) {
+    __shared__ int64_t s_ebeg[TAIL_THREADS];
+    __shared__ uint64_t s_inc[TAIL_THREADS];
+    __shared__ uint32_t s_pref[TAIL_THREADS + 1];
+    __shared__ uint32_t s_scan[TAIL_THREADS / 64];
+    __shared__ uint32_t s_next, s_count;
+    __shared__ unsigned long long s_dang;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t src = (uint32_t)d.src[q];
+    uint64_t *incs = d.inc_tab + (uint64_t)q * d.segq_cap;
+    uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
+    int L = L0;
+    uint32_t last_level = 0;
+    for (int done = 0; max_levels <= 0 || done < max_levels; done++, L++) {
+        const int par = L & 1;
+        if (tid == 0) {
+            s_count = __atomic_load_n(&d.fl_count[par][q * CSTRIDE], __ATOMIC_RELAXED);
+            s_next = 0;
+            s_dang = 0;
+        }
+        __syncthreads();
+        const uint32_t count = s_count;
+        if (!count) break;
+        if (L >= MAX_LEVELS) { if (tid == 0) atomicOr(d.err, ERR_WL_OVERFLOW); break; }
+        last_level = (uint32_t)L + 1;
+        const uint32_t *in = d.fl[par] + slab;
+        uint32_t *out = d.fl[par ^ 1] + slab;
+        // ---- all pops of the level (algo.h:983-1002)
+        for (uint32_t i = tid; i < count; i += TAIL_THREADS) {
+            const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
+            const uint64_t a = slab + v;
+            const uint64_t r = atomicExch((unsigned long long *)&d.residue[a], 0ull);   // algo.h:984-985
+            int64_t beg; uint64_t deg;
+            node_row(d, v, beg, deg);
+            const uint64_t keep = mulshift62(r, d.afix);
+            const uint64_t push = r - keep;
+            uint64_t inc = 0, res_add;
+            if (deg == 0) { res_add = keep; atomicAdd(&s_dang, (unsigned long long)push); } // algo.h:993-994
+            else {
+                inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg;   // algo.h:1002
+                res_add = keep + (push - inc * deg);
+            }
+            atomicAdd((unsigned long long *)&d.ppr[a], (unsigned long long)res_add);        // algo.h:986-989
+            incs[i] = inc;
+            acc_res += res_add;
+            acc_pops++;
+            acc_relax += deg;
+        }
+        __threadfence();
+        __syncthreads();
+        // ---- relaxations, a tile of TAIL_THREADS frontier nodes at a time (algo.h:1003-1016)
+        for (uint32_t tbase = 0; tbase < count; tbase += TAIL_THREADS) {
+            const uint32_t i = tbase + tid;
+            uint32_t cnt = 0;
+            if (i < count) {
+                const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
+                int64_t beg; uint64_t deg;
+                node_row(d, v, beg, deg);
+                s_ebeg[tid] = beg;
+                s_inc[tid] = __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
+                cnt = (uint32_t)deg;
+            }
+            uint32_t wtot;
+            const uint32_t wx = wave_excl_scan(cnt, wtot);
+            if (lane == 0) s_scan[wid] = wtot;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < TAIL_THREADS / 64; w++) { const uint32_t c = s_scan[w]; if (w < wid) before += c; total += c; }
+            s_pref[tid] = before + wx;
+            if (tid == 0) s_pref[TAIL_THREADS] = total;
+            __syncthreads();
+            for (uint32_t e = tid; e < total; e += TAIL_THREADS) {
+                uint32_t lo = 0, hi = TAIL_THREADS;
+#pragma unroll
+                for (int it = 0; it < 10; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                while (s_pref[lo + 1] <= e) lo++; // nodes without edges
+                const uint64_t inc = s_inc[lo];
+                if (!inc) continue;
+                const uint32_t w = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)inc);
+                const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                if (old < thr && old + inc >= thr) { // crossed in this level: next frontier (algo.h:1012-1015)
+                    const uint32_t pos = atomicAdd(&s_next, 1u);
+                    if (pos < (uint32_t)d.n) out[pos] = w; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- dangling mass back to the source (algo.h:994-998)
+        if (tid == 0 && s_dang) {
+            const uint64_t dm = s_dang;
+            const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + src], (unsigned long long)dm);
+            const uint64_t thr = node_thr(d.t1, d.deg[src]);
+            if (old < thr && old + dm >= thr) {
+                const uint32_t pos = atomicAdd(&s_next, 1u);
+                if (pos < (uint32_t)d.n) out[pos] = src; else atomicOr(d.err, ERR_WL_OVERFLOW);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            d.fl_count[par ^ 1][q * CSTRIDE] = s_next;
+            d.fl_count[par][q * CSTRIDE] = 0;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    acc_res = wave_sum(acc_res); acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
+    if (lane == 0 && acc_pops) {
+        QState *s = &d.qs[q];
+        atomicAdd(&s->reserved, (unsigned long long)acc_res);
+        atomicAdd(&s->pops, (unsigned long long)acc_pops);
+        if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
+    }
+    if (tid == 0 && last_level) d.qs[q].levels = last_level;
+}
+
 // grid = (bins of the pass, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
 // to the ppr slab and there is no threshold / frontier.
 template <bool TO_PPR>

@@ -245,7 +245,7 @@ def test_topk_argument_checks(engine, oracle, tiny):
 
 @pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow",
                                   "bucketed_wide_multipass", "bucketed_wide_multipass_unsorted",
-                                  "bucketed_wide_multipass_nosplit"])
+                                  "bucketed_wide_multipass_nosplit", "tail_early", "tail_wide_multipass"])
 def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
     """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
     overflow fallback all give the twin's bits (integer adds commute)."""
@@ -261,6 +261,13 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         mode = "bucketed_wide_multipass"
     if mode == "bucketed_wide_multipass_nosplit":  # every pass scans whole rows and filters by bin range
         monkeypatch.setenv("FORA_HIP_NO_SPLIT", "1")
+        mode = "bucketed_wide_multipass"
+    # the bucketed levels are what these modes are about: keep k_push_tail (which takes over once every frontier is
+    # small -- on a 32 k-node graph almost at once) out of them, except where it is the subject
+    monkeypatch.setenv("FORA_HIP_TAIL", "100000000" if mode.startswith("tail") else "0")
+    if mode.startswith("tail"):
+        monkeypatch.setenv("FORA_HIP_TAIL_ALWAYS", "1")
+    if mode == "tail_wide_multipass":
         mode = "bucketed_wide_multipass"
     if mode == "direct":
         monkeypatch.setenv("FORA_HIP_DIRECT", "1")
@@ -294,6 +301,8 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     monkeypatch.delenv("FORA_HIP_FORCE_WIDE", raising=False)
     monkeypatch.delenv("FORA_HIP_PASS_BINS", raising=False)
     monkeypatch.delenv("FORA_HIP_NO_SPLIT", raising=False)
+    monkeypatch.delenv("FORA_HIP_TAIL", raising=False)
+    monkeypatch.delenv("FORA_HIP_TAIL_ALWAYS", raising=False)
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
