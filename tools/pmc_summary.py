@@ -28,6 +28,7 @@ def main():
             res[k][c + "_KiB_total"] = v
             res[k][c + "_dispatches"] = n
             res[k][c + "_bytes_per_launch"] = v * 1024.0 / max(1, n)
+            res[k][c + "_bytes_total"] = v * 1024.0
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
         print(k, {a: round(b) for a, b in v.items() if a.endswith("per_launch")})
