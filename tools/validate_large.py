@@ -66,7 +66,7 @@ if len(sys.argv) > 5 and sys.argv[5] == "topk":
     total, _, _ = e.index_sizes()
     print(f"--opt index: {total} walks built in {time.time() - t0:.2f} s", flush=True)
     nk = min(len(srcs), 8)
-    e.topk(srcs[:2], 500, epsilon=0.5, with_idx=True)  # warm-up
+    e.topk(srcs[:nk], 500, epsilon=0.5, with_idx=True)  # warm-up with the same batch size (no re-allocation when timed)
     e.reset_timing()
     t0 = time.time()
     ids, sc, rounds = e.topk(srcs[:nk], 500, epsilon=0.5, with_idx=True)
