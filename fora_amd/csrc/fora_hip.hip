@@ -1143,6 +1143,11 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
     const double pfail = 1.0 / c->n / c->n;        // query.h:977
     const long long m = c->m_attr;
     (void)n_d;
+    if (!(init_delta >= min_delta)) { // k > n/10: the reference's round loop (query.h:1001) never runs, topk_ppr sees an empty ppr
+        for (size_t i = 0; i < (size_t)nq * k; i++) { ids[i] = 0; scores[i] = 0.0; }
+        if (rounds) for (int i = 0; i < nq; i++) rounds[i] = 0;
+        return FORA_OK;
+    }
     // omega of the last possible round bounds the walk work list
     const double omega_max = (2 + epsilon) * log(2 / pfail) / min_delta / epsilon / epsilon;
     int rc = ensure_workspace(c, nq, omega_max);

@@ -1,0 +1,88 @@
+"""Edge cases of the hot path on hand-made graphs, GPU vs twin bit for bit: empty batches, graphs without edges,
+hubs far above the per-item limits (PUSH of one node = thousands of relaxations, WALK_SEG = 1024 walks per item),
+duplicate edges (the reference keeps them, graph.h:151-161), repeated sources, extreme epsilon, extreme k."""
+import numpy as np
+import pytest
+
+from conftest import pick_sources
+
+pytestmark = pytest.mark.gpu
+SEED = 0x464F5241
+
+
+def _load(engine, g, **kw):
+    engine.clear_index()
+    engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+    engine.set_params(seed=SEED, **kw)
+    return engine.get_params()
+
+
+def _check_queries(engine, oracle, g, srcs, rmax, omega, **kw):
+    ppr, res, st = engine.query_fix(np.asarray(srcs, dtype=np.int32))
+    for i, s in enumerate(srcs):
+        want, wres, wst = oracle.twin_query(g, int(s), rmax, omega, seed=SEED, **kw)
+        assert (res[i] == wres).all() and (ppr[i] == want).all()
+        assert st[i]["ppr_sum_fix"] == oracle.FIX_ONE and st[i]["n_walks"] == wst["n_walks"]
+    return ppr
+
+
+def test_empty_batch_and_edgeless_graph(engine, oracle):
+    n = 10
+    g = oracle.Graph.from_edges(n, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))   # no edge at all: every node dangling
+    _load(engine, g, epsilon=0.5)
+    ppr, st = engine.query(np.zeros(0, dtype=np.int32))
+    assert ppr.shape == (0, n) and st == []
+    ppr, st = engine.query(np.array([3, 7], dtype=np.int32))
+    assert (ppr == np.eye(n)[[3, 7]]).all() and all(s["dangling_source"] == 1 and s["n_walks"] == 0 for s in st)  # algo.h:961-965
+    _, _, ids, sc = engine.power_iteration(np.array([4], dtype=np.int32), max_iter=5, k=3, want_ppr=False)
+    assert ids[0][0] == 4 and abs(sc[0][0] - (1 - 0.8 ** 5)) < 1e-12 and (sc[0][1:] == 0).all()
+
+
+def test_star_hub_and_duplicate_edges(engine, oracle):
+    """Hub with 6000 out-edges (each leaf points back twice -- duplicate edges count twice, graph.h:158-159), a chain
+    hanging off one leaf and a dangling end: thousands of relaxations and tens of thousands of walks per node."""
+    L = 6000
+    n = L + 4
+    src = [0] * L + [v for v in range(1, L + 1) for _ in range(2)] + [1, L + 1, L + 2]
+    dst = list(range(1, L + 1)) + [0] * (2 * L) + [L + 1, L + 2, L + 3]
+    g = oracle.Graph.from_edges(n, len(src), np.array(src, np.int32), np.array(dst, np.int32))
+    assert g.deg[0] == L and g.deg[2] == 2 and g.deg[1] == 3 and g.deg[L + 3] == 0
+    for eps in (0.5, 0.05):
+        rmax, omega = _load(engine, g, epsilon=eps)
+        ppr = _check_queries(engine, oracle, g, [0, 1, 2, L + 1, L + 3, 0], rmax, omega)
+        assert (ppr[0] == ppr[5]).all()                                  # a source may repeat inside a batch
+    engine.build_index()
+    idx = engine.get_index()
+    assert idx[2][0] == int(np.ceil(L * rmax * omega))                   # build.h:328: hub gets ceil(outdeg*rmax*omega) walks
+    pi, _, st = engine.query_fix(np.array([0, 5], dtype=np.int32), with_idx=True, want_residue=False)
+    for i, s in enumerate([0, 5]):
+        want, _, _ = oracle.twin_query(g, s, rmax, omega, seed=SEED, index=idx)
+        assert (pi[i] == want).all() and st[i]["n_idx_hit"] == st[i]["n_walks"]
+
+
+@pytest.mark.parametrize("eps", [0.02, 3.0])
+def test_extreme_epsilon(engine, oracle, tiny_dangling, eps):
+    g = tiny_dangling
+    rmax, omega = _load(engine, g, epsilon=eps)
+    srcs = list(pick_sources(g, 3, 201)) + list(pick_sources(g, 1, 202, want_dangling=True))
+    _check_queries(engine, oracle, g, srcs, rmax, omega)
+    _load(engine, g, epsilon=eps, opt=True)
+    rmax_o, omega_o = engine.get_params()
+    _check_queries(engine, oracle, g, srcs[:2], rmax_o, omega_o, opt=True)
+
+
+def test_extreme_k(engine, oracle, tiny):
+    g = tiny
+    _load(engine, g, epsilon=0.5, opt=True)
+    srcs = pick_sources(g, 3, 203)
+    # k > 1 (query.h:1318); 1024 = this build's cap; from k > n/10 the --opt driver's first delta 1/(10k) is below 1/n
+    # and the reference's round loop (query.h:1001) never runs: all-zero lists, zero rounds
+    for k in (2, 150, 1024):
+        ids, sc, rounds = engine.topk(srcs, k, epsilon=0.5)
+        bi, bs, br = engine.topk_bound(srcs, k, epsilon=0.5)
+        for i, s in enumerate(srcs):
+            wid, wsc, wr, _ = oracle.twin_topk_query(g, int(s), k, 0.5, seed=SEED)
+            assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+            assert (wr == 0) == (k > g.n // 10)
+            wid, wsc, wr, _, _, _ = oracle.twin_topk_bound_query(g, int(s), k, 0.5, seed=SEED)
+            assert br[i] == wr and (bi[i] == wid).all() and (bs[i] == wsc).all()
