@@ -22,6 +22,7 @@ static const char *const GEN_SS_QUERY = "generate-ss-query";
 static const char *const TOPK = "topk";
 static const char *const BUILD = "build";
 static const char *const GEN_EXACT_TOPK = "gen-exact-topk"; // config.h:37
+static const char *const BATCH_TOPK = "batch-topk";         // config.h:39
 static const char *const CHECK_GRAPH = "check-graph"; // not in the reference: loader self-check
 static const char *const CHECK_INDEX = "check-index"; // not in the reference: index file self-check (no GPU needed)
 static const char *const FORA = "fora";

@@ -43,6 +43,7 @@ static const char *HELP =
     "fora topk  --algo <algo> [options]\n"
     "fora build [options]\n"
     "fora gen-exact-topk [options]\n"
+    "fora batch-topk --algo <algo> [options]\n"
     "fora generate-ss-query [options]\n"
     "fora\n"
     "\n"
@@ -295,6 +296,34 @@ static int do_query(Graph &graph) { // query(), query.h:1415-1515 FORA branch
     return 0;
 }
 
+// one pass of get_topk (query.h:1139-1156) over the query list for the current config.k; lists come back in query order
+static int run_topk_pass(const Graph &graph, const std::vector<int32_t> &queries, unsigned query_size, const IndexData *index,
+                         std::vector<int32_t> &ids, std::vector<double> &scores, std::vector<int32_t> &rounds,
+                         std::vector<Shard> &shards) {
+    const size_t k = config.k;
+    ids.assign((size_t)query_size * k, 0);
+    scores.assign((size_t)query_size * k, 0.0);
+    rounds.assign(query_size, 0);
+    return run_sharded(graph, queries, query_size, index, shards, [&](fora_ctx *ctx, Shard &s) {
+        const size_t nl = s.sources.size();
+        std::vector<int32_t> lid(nl * k), lr(nl);
+        std::vector<double> lsc(nl * k);
+        // get_topk, query.h:1150-1153: --opt -> fora_query_topk_new, else fora_query_topk_with_bound
+        const int rc = config.opt ? fora_hip_topk_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon, config.rmax_scale,
+                                                        config.with_rw_idx, lid.data(), lsc.data(), lr.data())
+                                  : fora_hip_topk_bound_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon,
+                                                              config.rmax_scale, config.ppr_decay_alpha, config.with_rw_idx,
+                                                              lid.data(), lsc.data(), lr.data());
+        if (rc) return 1;
+        for (size_t i = 0; i < nl; i++) { // the "gather": top-k lists back in query order
+            std::copy(lid.begin() + (long)(i * k), lid.begin() + (long)((i + 1) * k), ids.begin() + (long)(s.pos[i] * k));
+            std::copy(lsc.begin() + (long)(i * k), lsc.begin() + (long)((i + 1) * k), scores.begin() + (long)(s.pos[i] * k));
+            rounds[s.pos[i]] = lr[i];
+        }
+        return 0;
+    });
+}
+
 static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch
     std::vector<int32_t> queries;
     if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); }
@@ -312,29 +341,10 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch
         }
     }
     load_exact_topk(); // query.h:1323
-    std::vector<int32_t> ids((size_t)query_size * config.k), rounds(query_size);
-    std::vector<double> scores((size_t)query_size * config.k);
+    std::vector<int32_t> ids, rounds;
+    std::vector<double> scores;
     std::vector<Shard> shards;
-    const size_t k = config.k;
-    if (run_sharded(graph, queries, query_size, config.with_rw_idx ? &index : nullptr, shards, [&](fora_ctx *ctx, Shard &s) {
-            const size_t nl = s.sources.size();
-            std::vector<int32_t> lid(nl * k), lr(nl);
-            std::vector<double> lsc(nl * k);
-            // get_topk, query.h:1150-1153: --opt -> fora_query_topk_new, else fora_query_topk_with_bound
-            const int rc = config.opt ? fora_hip_topk_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon, config.rmax_scale,
-                                                            config.with_rw_idx, lid.data(), lsc.data(), lr.data())
-                                      : fora_hip_topk_bound_batch(ctx, s.sources.data(), (int)nl, (int)k, config.epsilon,
-                                                                  config.rmax_scale, config.ppr_decay_alpha, config.with_rw_idx,
-                                                                  lid.data(), lsc.data(), lr.data());
-            if (rc) return 1;
-            for (size_t i = 0; i < nl; i++) { // the "gather": top-k lists back in query order
-                std::copy(lid.begin() + (long)(i * k), lid.begin() + (long)((i + 1) * k), ids.begin() + (long)(s.pos[i] * k));
-                std::copy(lsc.begin() + (long)(i * k), lsc.begin() + (long)((i + 1) * k), scores.begin() + (long)(s.pos[i] * k));
-                rounds[s.pos[i]] = lr[i];
-            }
-            return 0;
-        }))
-        return 1;
+    if (run_topk_pass(graph, queries, query_size, config.with_rw_idx ? &index : nullptr, ids, scores, rounds, shards)) return 1;
     double tot_walks = 0, tot_hits = 0;
     for (auto &s : shards) { tot_walks += (double)s.tm.walks; tot_hits += (double)s.tm.idx_hits; }
     long num_iter_topk = 0;
@@ -359,6 +369,61 @@ static int do_topk(Graph &graph) { // topk(), query.h:1309-1413 FORA branch
     timers.add(0, timers.get(FORA_QUERY));
     finish(graph, FORA_QUERY, query_size, tot_walks, tot_hits);
     cout << "top-k lists written to " << out << endl;
+    return 0;
+}
+
+static int do_batch_topk(Graph &graph) { // batch_topk(), query.h:1517-1640, FORA branch (:1612-1636): the algorithm runs again per k
+    std::vector<int32_t> queries;
+    if (!graph.load_ss_query(queries)) { cerr << graph.error << endl; exit(0); }
+    info("queries.size()", queries.size());
+    unsigned query_size = std::min<unsigned>((unsigned)queries.size(), config.query_size);
+    if (!(config.k < (unsigned)graph.n - 1) || !(config.k > 1)) { cerr << "k out of range" << endl; return 1; } // :1524-1525
+    info("config.k", config.k);
+    split_line();
+    load_exact_topk(); // :1529
+    IndexData index;
+    if (config.with_rw_idx) {
+        string err;
+        if (!IndexFile::read(config.graph_location, config.rmax_scale, config.opt, graph.n, index.rw, index.off, index.cnt, err)) {
+            cerr << err << endl;
+            return 1;
+        }
+    }
+    std::vector<unsigned> ks; // :1585-1591
+    const unsigned step = config.k / 5;
+    if (step > 0) for (unsigned i = 1; i < 5; i++) ks.push_back(i * step);
+    ks.push_back(config.k);
+    struct Pred { double precision = 0, recall = 0; int count = 0; };
+    std::map<unsigned, Pred> pred;
+    for (unsigned k : ks) {
+        if (k < 2) continue; // get_topk needs k > 1
+        config.k = k;
+        info("========================================", "");
+        info("k is set to be ", config.k);
+        result.topk_recall = 0; result.topk_precision = 0; result.real_topk_source_count = 0;
+        std::vector<int32_t> ids, rounds;
+        std::vector<double> scores;
+        std::vector<Shard> shards;
+        if (run_topk_pass(graph, queries, query_size, config.with_rw_idx ? &index : nullptr, ids, scores, rounds, shards)) return 1;
+        double wall = 0;
+        for (auto &s : shards) wall = std::max(wall, s.seconds);
+        for (unsigned i = 0; i < query_size; i++) {
+            cout << i + 1 << ". source node:" << queries[i] << endl;
+            compute_precision(queries[i], &ids[(size_t)i * k], &scores[(size_t)i * k], k);
+        }
+        pred[k].precision = result.topk_precision; pred[k].recall = result.topk_recall; pred[k].count = result.real_topk_source_count;
+        cout << "k=" << k << " precision=" << result.topk_precision / result.real_topk_source_count
+             << " recall=" << result.topk_recall / result.real_topk_source_count << endl;   // :1628-1629
+        cout << "Average query time (s):" << wall / query_size << endl;                   // :1630
+    }
+    split_line(); // display_precision_for_dif_k, algo.h:676-692
+    cout << config.algo << endl;
+    for (unsigned k : ks) cout << k << "\t";
+    cout << endl << "Precision:" << endl;
+    for (unsigned k : ks) cout << pred[k].precision / pred[k].count << "\t";
+    cout << endl << "Recall:" << endl;
+    for (unsigned k : ks) cout << pred[k].recall / pred[k].count << "\t";
+    cout << endl;
     return 0;
 }
 
@@ -488,16 +553,16 @@ int main(int argc, char *argv[]) {
 
     const string act = config.action;
     if (act != QUERY && act != TOPK && act != BUILD && act != GEN_SS_QUERY && act != CHECK_GRAPH && act != GEN_EXACT_TOPK &&
-        act != CHECK_INDEX) {
+        act != CHECK_INDEX && act != BATCH_TOPK) {
         cerr << "sub command not regoznized" << endl; // fora.cpp:278-281
         return 1;
     }
-    if ((act == QUERY || act == TOPK) && config.algo != FORA) { // fora.cpp:169-175
+    if ((act == QUERY || act == TOPK || act == BATCH_TOPK) && config.algo != FORA) { // fora.cpp:169-175, :226-231
         info("Wrong algo param: ", config.algo);
         cerr << "only --algo fora is part of this build" << endl;
         return 1;
     }
-    if ((act == QUERY || act == TOPK || act == BUILD) && !(config.epsilon > 0)) { cerr << "--epsilon must be > 0" << endl; return 1; }
+    if ((act == QUERY || act == TOPK || act == BUILD || act == BATCH_TOPK) && !(config.epsilon > 0)) { cerr << "--epsilon must be > 0" << endl; return 1; }
     config.graph_location = config.get_graph_folder();
     Graph graph;
     graph.data_folder = config.graph_location;
@@ -547,6 +612,7 @@ int main(int argc, char *argv[]) {
     } else if (act == QUERY) rc = do_query(graph);
     else if (act == TOPK) rc = do_topk(graph);
     else if (act == GEN_EXACT_TOPK) rc = do_gen_exact_topk(graph);
+    else if (act == BATCH_TOPK) rc = do_batch_topk(graph);
     else if (act == BUILD) { const double t0 = now_s(); rc = do_build(graph); timers.add(0, now_s() - t0); }
     if (rc) return rc;
     timers.show(); // fora.cpp:282

@@ -46,6 +46,8 @@ def test_help_and_bad_flags(cli):
     assert r.returncode == 1 and "sub command not regoznized" in r.stderr         # fora.cpp:278-281
     r = _run([cli, "query", "--algo", "bippr", "--epsilon", "0.5"])
     assert r.returncode == 1
+    r = _run([cli, "batch-topk", "--algo", "mc", "--epsilon", "0.5"])
+    assert r.returncode == 1
 
 
 def test_loader_matches_oracle(cli, oracle, tiny, tmp_path):
@@ -218,6 +220,14 @@ def test_cli_gen_exact_topk_and_precision(cli, oracle, small, tmp_path):
     assert abs(float(j["result"]["topk precision"]) - prec / 4) < 1e-12
     assert abs(float(j["result"]["topk recall"]) - rec / 4) < 1e-12
     assert float(j["result"]["topk precision"]) >= 0.8
+    # batch-topk (query.h:1517-1640): the algorithm again for k/5, 2k/5, ..., k; precision table at the end
+    r = _run([cli, "batch-topk", "--algo", "fora", "--opt", "--epsilon", "0.5", "--k", str(k), "--query_size", "4", *common])
+    assert r.returncode == 0, r.stderr
+    for kk in (4, 8, 12, 16, 20):
+        assert f"k is set to be ={kk}" in r.stdout and f"k={kk} precision=" in r.stdout
+    tail = r.stdout.strip().split("\n")[-6:]
+    assert tail[0] == "fora" and tail[1].split() == ["4", "8", "12", "16", "20"] and tail[2] == "Precision:" and tail[4] == "Recall:"
+    assert abs(float(tail[3].split()[-1]) - prec / 4) < 1e-5            # the k = 20 column is the topk run above
 
 
 def _fnv(rw, off, cnt):
