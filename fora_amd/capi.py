@@ -34,6 +34,11 @@ class QueryStats(C.Structure):
                 ("reserved_", C.c_int32)]
 
 
+_STATS_DTYPE = np.dtype([(name, {C.c_double: np.float64, C.c_uint64: np.uint64, C.c_int32: np.int32}[ct])
+                         for name, ct in QueryStats._fields_], align=True)
+assert _STATS_DTYPE.itemsize == C.sizeof(QueryStats)
+
+
 class Timing(C.Structure):
     _fields_ = [("push_pop_ms", C.c_double), ("push_expand_ms", C.c_double), ("push_accum_ms", C.c_double), ("walk_alloc_ms", C.c_double),
                 ("walk_ms", C.c_double), ("walk_accum_ms", C.c_double), ("other_ms", C.c_double), ("batch_ms", C.c_double),
@@ -154,8 +159,10 @@ class Engine:
 
     # ---- queries
     @staticmethod
-    def _stats(arr):
-        return [{k: getattr(s, k) for k, _ in QueryStats._fields_} for s in arr]
+    def _stats(arr, n):
+        # one structured-array copy instead of a dict per query (1000 queries: ~4 ms of getattr otherwise);
+        # st[i]["pops"], iteration and len() work as they would on a list of dicts
+        return np.frombuffer(arr, dtype=_STATS_DTYPE, count=n).copy()
 
     def query(self, sources, with_idx=False, want_ppr=True):
         src = np.ascontiguousarray(sources, dtype=np.int32)
@@ -164,7 +171,7 @@ class Engine:
         out = np.zeros((nq, self.n), dtype=np.float64) if want_ppr else None
         self._chk(self._lib.fora_hip_query_batch(self._ctx, _p(src), C.c_int(nq), C.c_int(int(with_idx)),
                                                  _p(out), st))
-        return out, self._stats(st[:nq])
+        return out, self._stats(st, nq)
 
     def query_fix(self, sources, with_idx=False, want_residue=True):
         src = np.ascontiguousarray(sources, dtype=np.int32)
@@ -174,7 +181,7 @@ class Engine:
         res = np.zeros((nq, self.n), dtype=np.uint64) if want_residue else None
         self._chk(self._lib.fora_hip_query_batch_fix(self._ctx, _p(src), C.c_int(nq), C.c_int(int(with_idx)),
                                                      _p(ppr), _p(res), st))
-        return ppr, res, self._stats(st[:nq])
+        return ppr, res, self._stats(st, nq)
 
     def push(self, sources):
         src = np.ascontiguousarray(sources, dtype=np.int32)
@@ -183,7 +190,7 @@ class Engine:
         rsv = np.zeros((nq, self.n), dtype=np.uint64)
         res = np.zeros((nq, self.n), dtype=np.uint64)
         self._chk(self._lib.fora_hip_push_batch(self._ctx, _p(src), C.c_int(nq), _p(rsv), _p(res), st))
-        return rsv, res, self._stats(st[:nq])
+        return rsv, res, self._stats(st, nq)
 
     def topk(self, sources, k, epsilon=0.5, rmax_scale=1.0, with_idx=False):
         src = np.ascontiguousarray(sources, dtype=np.int32)

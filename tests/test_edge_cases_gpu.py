@@ -31,7 +31,7 @@ def test_empty_batch_and_edgeless_graph(engine, oracle):
     g = oracle.Graph.from_edges(n, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))   # no edge at all: every node dangling
     _load(engine, g, epsilon=0.5)
     ppr, st = engine.query(np.zeros(0, dtype=np.int32))
-    assert ppr.shape == (0, n) and st == []
+    assert ppr.shape == (0, n) and len(st) == 0
     ppr, st = engine.query(np.array([3, 7], dtype=np.int32))
     assert (ppr == np.eye(n)[[3, 7]]).all() and all(s["dangling_source"] == 1 and s["n_walks"] == 0 for s in st)  # algo.h:961-965
     _, _, ids, sc = engine.power_iteration(np.array([4], dtype=np.int32), max_iter=5, k=3, want_ppr=False)
