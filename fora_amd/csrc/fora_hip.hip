@@ -169,7 +169,12 @@ void free_workspace(fora_ctx *c) {
 }
 
 constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
-static unsigned walk_grid_x(int nq) { return (unsigned)std::min(2048, std::max(8, 8192 / std::max(1, nq))); }
+static unsigned walk_grid_x(int nq) {
+    if (const char *e = getenv("FORA_HIP_WX")) if (atoi(e) > 0) return (unsigned)atoi(e);
+    // ~24 k workgroups per launch (1280 are resident): ws at 1000 slots, blocks per slot 4 -> 552 ms, 8 -> 509,
+    // 16 -> 493, 24 -> 489, 32 -> 495 per 3000 queries
+    return (unsigned)std::min(2048, std::max(16, 24576 / std::max(1, nq)));
+}
 
 constexpr int SPEC = 3;          // levels launched ahead of the frontier-size readback
 constexpr int FLC_RING = SPEC + 2;
@@ -415,7 +420,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     int rc = FORA_OK;
     int L = 0;
     const int nq = d.nq;
-    unsigned xb = (unsigned)std::min(1024, std::max(8, 8192 / std::max(1, nq)));
+    unsigned xb = (unsigned)std::min(1024, std::max(16, 16384 / std::max(1, nq))); // blocks per slot; ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
     if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
     uint32_t tail_max = 1024; // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
     if (const char *e = getenv("FORA_HIP_TAIL")) tail_max = (uint32_t)std::max(0, atoi(e));
