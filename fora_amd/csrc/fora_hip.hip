@@ -169,6 +169,15 @@ void free_workspace(fora_ctx *c) {
 }
 
 constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
+// workgroups per slot of the kernels that sweep a slot's slab (walk allocation, top-k frontier / copy / count): ~32 k
+// workgroups per launch; one per 256 nodes (up to 1 M tiny workgroups at 1000 slots) cost k_walk_alloc 19 ms instead of
+// 8 per 3000 ws queries
+static uint32_t slab_grid_x(const fora_ctx *c, int nq) {
+    const int64_t nchunk = ((int64_t)c->n + BLOCK - 1) / BLOCK;
+    int64_t x = std::min<int64_t>(1024, std::max<int64_t>(16, 32768 / std::max(1, nq)));
+    if (const char *e = getenv("FORA_HIP_AX")) if (atoi(e) > 0) x = atoi(e);
+    return (uint32_t)std::max<int64_t>(1, std::min(x, nchunk));
+}
 static unsigned walk_grid_x(int nq) {
     if (const char *e = getenv("FORA_HIP_WX")) if (atoi(e) > 0) return (unsigned)atoi(e);
     // ~24 k workgroups per launch (1280 are resident): ws at 1000 slots, blocks per slot 4 -> 552 ms, 8 -> 509,
@@ -578,7 +587,7 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
 // from 8*config.rmax; a slot keeps going while its estimated walk cost exceeds what its push has cost so far.
 int push_balanced(fora_ctx *c, const int32_t *sources, int nq, bool with_idx) {
     if (!c->d_active) HIPCHK(c, hipMalloc(&c->d_active, (size_t)c->B));
-    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
     Dev d = make_dev(c, nq, with_idx);
     int h = ev_begin(c, 4);
     hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
@@ -644,7 +653,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
     }
     if (rc) return rc;
     if (!(flags & RUN_PUSH_ONLY)) {
-        const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+        const uint32_t chunks = slab_grid_x(c, nq);
         h = ev_begin(c, 2);
         hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
                            (const uint8_t *)nullptr, (uint64_t *)nullptr, (unsigned long long *)nullptr);
@@ -1171,7 +1180,7 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
         HIPCHK(c, hipMalloc(&c->d_topk_sc, (size_t)c->B * k * 8));
         c->topk_cap = c->B * k;
     }
-    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
     std::vector<uint8_t> active;
     std::vector<unsigned long long> above;
     for (int b0 = 0; b0 < nq; b0 += c->B) {
@@ -1319,7 +1328,7 @@ int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k
         HIPCHK(c, hipMalloc(&c->d_lb_sc, (size_t)c->B * k * 8));
         c->lb_cap = c->B * k;
     }
-    const uint32_t chunks = (uint32_t)std::min<int64_t>(((int64_t)c->n + BLOCK - 1) / BLOCK, 1024);
+    const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
     std::vector<uint8_t> active;
     std::vector<unsigned long long> above;
     std::vector<uint32_t> failv;
