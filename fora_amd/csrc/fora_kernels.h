@@ -34,7 +34,10 @@ constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
 constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
 constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-B push messages (target, increment)
-constexpr int ACC_THREADS = 512;
+#ifndef FORA_ACC_THREADS
+#define FORA_ACC_THREADS 512
+#endif
+constexpr int ACC_THREADS = FORA_ACC_THREADS;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_popbin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
