@@ -40,6 +40,9 @@ constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-
 constexpr int ACC_THREADS = FORA_ACC_THREADS;
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_popbin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
+// bucket messages are read exactly once: non-temporal loads keep them from displacing the increment table and the
+// slabs in L2 (accumulate kernels -1 %)
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
 // Narrow layout: a walk result travels as ONE 64-bit word, node id (< 2^20) | weight << 20 (weights are r / num_s_rw,
 // about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
@@ -897,12 +900,12 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mw[k] = packed ? 0u : d.bk_w[bk0 + (i < cnt ? i : 0)];
+            mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
         }
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : d.bk_inc[bk0 + (i < cnt ? i : 0)];
+            mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[bk0 + (i < cnt ? i : 0)]);
         }
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
