@@ -103,6 +103,8 @@ struct fora_ctx {
     // k+1 overlap the (fabric-bound) walks of batch k
     fora_ctx *twin = nullptr;
     bool is_twin = false;
+    uint32_t bk_scale = 1;        // bucket capacity multiplier, doubled after a bucket overflow (see with_bucket_retry)
+    bool bucket_overflow = false; // the last device error was ERR_BUCKET_OVERFLOW
     // --balanced (query.h:848-884): cost model in seconds
     bool balanced = false;
     double c_pop = 2.0e-11, c_edge = 2.4e-11, t_walk = 6.5e-11, t_idx = 2.2e-11, bal_start = 8;
@@ -229,7 +231,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
         p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins()) : p.nbins;
-        p.bk_cap = want_wide(c) ? want_bk_cap_wide() : want_bk_cap();
+        p.bk_cap = (uint32_t)std::min<uint64_t>((uint64_t)(want_wide(c) ? want_bk_cap_wide() : want_bk_cap()) * c->bk_scale, 1u << 28);
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
@@ -302,6 +304,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
         HIPCHK(c, hipMalloc(&c->d_inc_tab, (uint64_t)B * p.segq_cap * 8));
         c->ov_cap = (uint32_t)std::max<uint64_t>(262144, n / 8); // bucket-overflow list, scales with the graph
+        if (const char *e = getenv("FORA_HIP_OVCAP")) if (atoi(e) > 0) c->ov_cap = (uint32_t)atoi(e); // tests
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
@@ -411,6 +414,7 @@ int check_dev_err(fora_ctx *c) {
     uint32_t e = 0;
     HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bucket_overflow = (e & ERR_BUCKET_OVERFLOW) != 0;
     if (e) {
         char buf[96];
         snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x%s)", e,
@@ -731,6 +735,7 @@ int sync_twin(fora_ctx *c) {
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
     w->idx_len = c->idx_len; w->have_index = c->have_index;
+    w->bk_scale = c->bk_scale;
     w->balanced = c->balanced; w->bal_start = c->bal_start; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
     w->batch_req = c->B; // same slot count as the first lane
     return FORA_OK;
@@ -802,6 +807,23 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
 }
 
 } // namespace
+
+// A batch whose message buckets (and their overflow list) were too small is not a caller error: double the bucket
+// capacity, re-plan the workspace and run the call again from scratch (results never depend on the capacity).
+template <class F> int with_bucket_retry(fora_ctx *c, F call) {
+    for (;;) {
+        const int rc = call();
+        if (!c || rc != FORA_E_OVERFLOW) return rc;
+        const bool bucket = c->bucket_overflow || (c->twin && c->twin->bucket_overflow);
+        if (!bucket || c->bk_scale >= (1u << 16)) return rc;
+        c->bk_scale *= 2;
+        c->bucket_overflow = false;
+        if (c->twin) { c->twin->bucket_overflow = false; }
+        (void)hipSetDevice(c->device);
+        free_workspace(c);
+        if (c->twin) free_workspace(c->twin);
+    }
+}
 
 // =============================================================================== C ABI
 extern "C" {
@@ -885,6 +907,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     if (c->twin) free_workspace(c->twin);
     free_index(c);
     free_graph(c);
+    c->bk_scale = 1;
     std::vector<uint64_t> rowinfo((size_t)n);
     std::vector<uint32_t> deg((size_t)n);
     for (int32_t v = 0; v < n; v++) {
@@ -1075,17 +1098,17 @@ int fora_hip_clear_index(fora_ctx *c) {
 // ---- queries -------------------------------------------------------------------
 int fora_hip_query_batch(fora_ctx *c, const int32_t *sources, int nq, int with_idx, double *ppr_out,
                          fora_query_stats *stats) {
-    return query_common(c, sources, nq, with_idx, 0, ppr_out, nullptr, nullptr, stats);
+    return with_bucket_retry(c, [&] { return query_common(c, sources, nq, with_idx, 0, ppr_out, nullptr, nullptr, stats); });
 }
 
 int fora_hip_query_batch_fix(fora_ctx *c, const int32_t *sources, int nq, int with_idx, uint64_t *ppr_fix_out,
                              uint64_t *residue_fix_out, fora_query_stats *stats) {
-    return query_common(c, sources, nq, with_idx, 0, nullptr, ppr_fix_out, residue_fix_out, stats);
+    return with_bucket_retry(c, [&] { return query_common(c, sources, nq, with_idx, 0, nullptr, ppr_fix_out, residue_fix_out, stats); });
 }
 
 int fora_hip_push_batch(fora_ctx *c, const int32_t *sources, int nq, uint64_t *reserve_fix_out,
                         uint64_t *residue_fix_out, fora_query_stats *stats) {
-    return query_common(c, sources, nq, 0, RUN_PUSH_ONLY, nullptr, reserve_fix_out, residue_fix_out, stats);
+    return with_bucket_retry(c, [&] { return query_common(c, sources, nq, 0, RUN_PUSH_ONLY, nullptr, reserve_fix_out, residue_fix_out, stats); });
 }
 
 int fora_hip_walk_counts(fora_ctx *c, const double *residue, double rsum, uint64_t *num_s_rw, uint64_t *n_rw) {
@@ -1137,8 +1160,14 @@ int fora_hip_walks(fora_ctx *c, uint32_t stream_id, uint32_t round, int no_zero_
 
 // top-k driver: fora_query_topk_new (query.h:972-1045) for a batch of slots.  All active slots
 // are in the same round, so delta / rmax / omega are uniform per round; finished slots drop out.
+static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                           int with_idx, int32_t *ids, double *scores, int32_t *rounds);
 int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
                         int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
+    return with_bucket_retry(c, [&] { return topk_batch_impl(c, sources, nq, k, epsilon, rmax_scale, with_idx, ids, scores, rounds); });
+}
+static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                           int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
     if (!c) return FORA_E_ARG;
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha, seed)");
@@ -1277,8 +1306,16 @@ int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, doub
 // top-k with bounds: fora_query_topk_with_bound (query.h:909-969) for a batch of slots.  As in the --opt driver all
 // active slots share a round (delta halves per round), finished slots drop out.  zero_ppr_upper_bound (query.h:935,
 // :748) only ever feeds itself in the reference and is not kept.
+static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                                 double ppr_decay_alpha, int with_idx, int32_t *ids, double *scores, int32_t *rounds);
 int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
                               double ppr_decay_alpha, int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
+    return with_bucket_retry(c, [&] {
+        return topk_bound_batch_impl(c, sources, nq, k, epsilon, rmax_scale, ppr_decay_alpha, with_idx, ids, scores, rounds);
+    });
+}
+static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
+                                 double ppr_decay_alpha, int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
     if (!c) return FORA_E_ARG;
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha, seed)");
@@ -1447,8 +1484,14 @@ int fora_hip_topk_bound_batch(fora_ctx *c, const int32_t *sources, int nq, int k
 
 // gen_exact_topk's kernel (query.h:1192-1238): the push with threshold = one unit per out-edge and a fixed
 // number of levels; what it reserves is the exact PPR up to (1-alpha)^max_iter.
+static int power_iteration_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int max_iter, double *ppr_out,
+                                      uint64_t *ppr_fix_out, int k, int32_t *ids, double *scores);
 int fora_hip_power_iteration_batch(fora_ctx *c, const int32_t *sources, int nq, int max_iter, double *ppr_out,
                                    uint64_t *ppr_fix_out, int k, int32_t *ids, double *scores) {
+    return with_bucket_retry(c, [&] { return power_iteration_batch_impl(c, sources, nq, max_iter, ppr_out, ppr_fix_out, k, ids, scores); });
+}
+static int power_iteration_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int max_iter, double *ppr_out,
+                                      uint64_t *ppr_fix_out, int k, int32_t *ids, double *scores) {
     if (!c) return FORA_E_ARG;
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     if (!c->have_params) return fail(c, FORA_E_ARG, "set_params first (alpha)");
