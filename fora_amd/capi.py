@@ -16,7 +16,7 @@ SYMBOLS = [
     "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_set_balanced", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",
     "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_topk_bound_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
-    "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing",
+    "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing", "fora_hip_get_stamps",
 ]
 
 
@@ -52,7 +52,8 @@ class Timing(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfora_hip.so")
+    # FORA_HIP_LIB: experiment tooling only (tools/pushbench.py times several builds of the library)
+    return os.environ.get("FORA_HIP_LIB") or os.path.join(_HERE, "libfora_hip.so")
 
 
 def load():
@@ -183,13 +184,16 @@ class Engine:
                                                      _p(ppr), _p(res), st))
         return ppr, res, self._stats(st, nq)
 
-    def push(self, sources):
+    def push(self, sources, want=True):
+        """want=False: only the per-query stats come back (the slabs stay in HBM)."""
         src = np.ascontiguousarray(sources, dtype=np.int32)
         nq = src.size
         st = (QueryStats * max(1, nq))()
-        rsv = np.zeros((nq, self.n), dtype=np.uint64)
-        res = np.zeros((nq, self.n), dtype=np.uint64)
+        rsv = np.zeros((nq, self.n), dtype=np.uint64) if want else None
+        res = np.zeros((nq, self.n), dtype=np.uint64) if want else None
         self._chk(self._lib.fora_hip_push_batch(self._ctx, _p(src), C.c_int(nq), _p(rsv), _p(res), st))
+        if not want:
+            return self._stats(st, nq)
         return rsv, res, self._stats(st, nq)
 
     def topk(self, sources, k, epsilon=0.5, rmax_scale=1.0, with_idx=False):
@@ -258,3 +262,9 @@ class Engine:
         t = Timing()
         self._chk(self._lib.fora_hip_get_timing(self._ctx, C.byref(t)))
         return t.as_dict()
+
+    def stamps(self):
+        """Diagnostic builds (-DFORA_STAMPS): cycles per kernel phase; zeros otherwise."""
+        out = np.zeros(32, dtype=np.uint64)
+        self._chk(self._lib.fora_hip_get_stamps(self._ctx, _p(out)))
+        return out

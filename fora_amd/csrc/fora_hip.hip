@@ -66,11 +66,12 @@ struct fora_ctx {
     QState *d_qs = nullptr;
     int32_t *d_src = nullptr;
     uint32_t *d_err = nullptr;
+    unsigned long long *d_stamps = nullptr; // diagnostic builds (-DFORA_STAMPS)
     // bucketed push (n <= MAX_BINS * BIN_SIZE)
     bool binned = false;
     int nbins = 0, pbins = 0; // bins of the graph; bins per pass (bucket-array stride)
     uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
-    uint64_t *d_inc_tab = nullptr;
+    uint64_t *d_inc_tab[2] = {nullptr, nullptr};
     uint32_t *d_ov_w = nullptr, *d_ov_count = nullptr; // bucket overflow list
     uint64_t *d_ov_inc = nullptr;
     uint32_t ov_cap = 0;
@@ -157,7 +158,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
     dfree(c->d_nz_counts);
     c->topk_cap = 0;
-    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
+    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
@@ -234,7 +235,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
         p.bk_cap = (uint32_t)std::min<uint64_t>((uint64_t)(want_wide(c) ? want_bk_cap_wide() : want_bk_cap()) * c->bk_scale, 1u << 28);
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -243,7 +244,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
 }
 
 // Multi-pass graphs (more bins than one pass holds): row-sorted copy of col + per-row split offsets, so that every
-// pass of k_pushq_popbin reads only its own part of each popped row.  Built once per (graph, pass size).
+// pass of k_pushq_bin reads only its own part of each popped row.  Built once per (graph, pass size).
 int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
     const int npass = pbins > 0 ? (nbins + pbins - 1) / pbins : 1;
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
@@ -302,7 +303,8 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_fl[0], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl[1], slab * 4));
         HIPCHK(c, hipMalloc(&c->d_fl_count, (size_t)B * 2 * 4 * CSTRIDE));
-        HIPCHK(c, hipMalloc(&c->d_inc_tab, (uint64_t)B * p.segq_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_inc_tab[0], (uint64_t)B * p.segq_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_inc_tab[1], (uint64_t)B * p.segq_cap * 8));
         c->ov_cap = (uint32_t)std::max<uint64_t>(262144, n / 8); // bucket-overflow list, scales with the graph
         if (const char *e = getenv("FORA_HIP_OVCAP")) if (atoi(e) > 0) c->ov_cap = (uint32_t)atoi(e); // tests
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
@@ -368,7 +370,9 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     if (const char *e = getenv("FORA_HIP_TINY")) if (atoi(e) >= 0) d.tiny_max = (uint32_t)atoi(e);
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
-    d.inc_tab = c->d_inc_tab; d.segq_cap = c->segq_cap;
+    d.inc_tab[0] = c->d_inc_tab[0]; d.inc_tab[1] = c->d_inc_tab[1]; d.segq_cap = c->segq_cap;
+    d.pop_next = 1;
+    d.stamps = c->d_stamps;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
     d.ov_count[0] = c->d_ov_count; d.ov_count[1] = c->d_ov_count ? c->d_ov_count + (size_t)c->B * CSTRIDE : nullptr;
     d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap;
@@ -448,9 +452,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
                 dp.pass = lo / c->pbins;
+                dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 int h = ev_begin(c, 1);
-                if (d.wide) hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
-                else hipLaunchKernelGGL(k_pushq_popbin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
                 hipLaunchKernelGGL(k_accum<false>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
@@ -528,9 +533,9 @@ int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, doubl
     uint32_t *ccount = c->d_nz_counts + (size_t)c->B * NZ_X;
     hipLaunchKernelGGL(k_nz_count, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, c->d_nz_counts);
     hipLaunchKernelGGL(k_nz_write, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, (const uint32_t *)c->d_nz_counts, c->d_fl[0],
-                       c->d_inc_tab, ccount);
+                       c->d_inc_tab[0], ccount);
     hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, ids, scores, raw,
-                       (const uint32_t *)c->d_fl[0], (const uint64_t *)c->d_inc_tab, (const uint32_t *)ccount);
+                       (const uint32_t *)c->d_fl[0], (const uint64_t *)c->d_inc_tab[0], (const uint32_t *)ccount);
     return FORA_OK;
 }
 
@@ -736,6 +741,7 @@ int sync_twin(fora_ctx *c) {
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
     w->idx_len = c->idx_len; w->have_index = c->have_index;
     w->bk_scale = c->bk_scale;
+    w->d_stamps = c->d_stamps;
     w->balanced = c->balanced; w->bal_start = c->bal_start; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
     w->batch_req = c->B; // same slot count as the first lane
     return FORA_OK;
@@ -854,6 +860,12 @@ int fora_hip_create(int device, fora_ctx **out) {
         delete c;
         return FORA_E_NOGPU;
     }
+    if (hipMalloc(&c->d_stamps, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_stamps, 0, 32 * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return FORA_E_NOMEM;
+    }
     const char *p = getenv("FORA_HIP_PROFILE");
     if (p && p[0] == '0') c->profiling = false;
     const char *g = getenv("FORA_HIP_GRID");
@@ -878,6 +890,7 @@ void fora_hip_destroy(fora_ctx *c) {
     free_workspace(c);
     free_index(c);
     free_graph(c);
+    dfree(c->d_stamps);
     for (auto &p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1549,6 +1562,14 @@ int fora_hip_reset_timing(fora_ctx *c) {
     if (!c) return FORA_E_ARG;
     c->timing = fora_timing{};
     if (c->twin) c->twin->timing = fora_timing{};
+    (void)hipSetDevice(c->device);
+    (void)hipMemset(c->d_stamps, 0, 32 * sizeof(unsigned long long));
+    return FORA_OK;
+}
+int fora_hip_get_stamps(fora_ctx *c, uint64_t *out32) {
+    if (!c || !out32) return FORA_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out32, c->d_stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FORA_OK;
 }
 int fora_hip_get_timing(fora_ctx *c, fora_timing *out) {

@@ -1,7 +1,7 @@
 // fora_kernels.h -- device-side data layout and kernels of the FORA SSPPR engine (gfx950, wave64).
 //
 // Hot path of wangsibovictor/fora re-designed for MI355X (citations into the reference):
-//   forward push    algo.h:954-1018   -> k_pushq_popbin<NB> + k_accum<false>, one pair per level and bin pass
+//   forward push    algo.h:954-1018   -> k_pushq_bin<NB> + k_accum<false>, one pair per level and bin pass
 //                                        (k_push_pop + k_push_expand: the one-atomic-per-edge form, test reference)
 //   walk allocation query.h:270-287   -> k_walk_alloc<MODE>
 //   random walks    algo.h:124-166, query.h:288-323 -> k_walk_idx<NB>, k_walk_online<MODE>, k_accum<true>
@@ -38,7 +38,7 @@ constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-
 #define FORA_ACC_THREADS 512
 #endif
 constexpr int ACC_THREADS = FORA_ACC_THREADS;
-constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_popbin / k_walk_idx
+constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 // bucket messages are read exactly once: non-temporal loads keep them from displacing the increment table and the
 // slabs in L2 (accumulate kernels -1 %)
@@ -72,7 +72,10 @@ struct WalkItem {     // <=WALK_SEG walks that start at one residue node
 
 struct QState {       // per-slot accumulators
     unsigned long long reserved; // sum of reserve so far; rsum_fix = FIX_ONE - reserved (algo.h:992)
-    unsigned long long dang;     // dangling mass waiting to return to the source (algo.h:994)
+    // dangling mass waiting to return to the source (algo.h:994).  Bucketed push: [L & 1] is delivered by the accumulate
+    // of level L while that same launch collects the mass of the nodes it pops for level L + 1 in the other word;
+    // the direct path uses [0] only
+    unsigned long long dang[2];
     unsigned long long pops, relax;
     unsigned long long n_walks, n_hit, n_rw, ppr_sum;
     uint32_t levels, dangling_source;
@@ -127,7 +130,11 @@ struct Dev {
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
-    uint64_t *inc_tab;      // [slot][segq_cap] increment of the node at frontier position i (gathered by k_accum)
+    // [slot][segq_cap] increment of the node at frontier position i, ping-pong like fl: the accumulate of level L
+    // gathers from [L & 1] while it writes the entries of the nodes it pops for level L + 1 into the other one
+    uint64_t *inc_tab[2];
+    unsigned long long *stamps; // diagnostic builds (-DFORA_STAMPS): cycles per kernel phase, [0..15] bin kernel, [16..31] accumulate
+    int32_t pop_next;       // k_accum<false>: pop the crossing nodes for the next level (0 on the last level of a capped run)
     uint64_t segq_cap;      // = n: a frontier holds each node at most once
     uint32_t *bk_w;         // [slot][bin][bk_cap] target node of a pending increment
     uint64_t *bk_inc;       // [slot][bin][bk_cap] its value
@@ -143,6 +150,14 @@ struct Dev {
 };
 
 // ------------------------------------------------------------------ helpers
+// Diagnostic build: thread 0 of a workgroup adds the shader-clock cycles since the previous stamp to d.stamps[slot].
+#ifdef FORA_STAMPS
+#define STAMP_DECL long long st_t_ = clock64();
+#define STAMP(slot) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(&d.stamps[slot], (unsigned long long)(n_ - st_t_)); st_t_ = n_; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(slot) do {} while (0)
+#endif
 __device__ __forceinline__ uint64_t mulshift62(uint64_t r, uint64_t a) {
     return (__umul64hi(r, a) << 2) | ((r * a) >> 62);
 }
@@ -166,6 +181,19 @@ __device__ __forceinline__ uint64_t node_thr(uint64_t t1, uint32_t deg) {
     if (deg == 0) return 1;
     uint64_t hi = __umul64hi(t1, (uint64_t)deg);
     return hi ? ~0ull : t1 * (uint64_t)deg;
+}
+
+// One pop (algo.h:983-1002): the node gives up residue r, keeps alpha of it as reserve, and every out-edge gets
+// inc = ((1-alpha)*r)/outdeg (returned).  The integer-division remainder stays reserved; a dangling node's
+// (1-alpha)*r goes back to the source (algo.h:993-994) through `dang`.
+__device__ __forceinline__ uint64_t pop_value(uint64_t afix, uint64_t r, uint32_t deg, uint64_t &res_add, uint64_t &dang) {
+    const uint64_t keep = mulshift62(r, afix); // v_residue * alpha
+    const uint64_t push = r - keep;            // (1-alpha) * v_residue
+    if (deg == 0) { res_add = keep; dang = push; return 0; }
+    const uint64_t inc = div_u64_u32(push, deg);
+    res_add = keep + (push - inc * deg);
+    dang = 0;
+    return inc;
 }
 
 __device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg, uint64_t &deg) {
@@ -299,23 +327,23 @@ __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
     if (q >= d.nq) return;
     QState z = {};
     const uint32_t s = (uint32_t)d.src[q];
-    int64_t beg; uint64_t deg;
-    node_row(d, s, beg, deg);
+    const uint32_t deg = d.deg[s];
+    const uint64_t a = (uint64_t)q * d.n + s;
     if (deg == 0 && mode != 2) {
-        d.ppr[(uint64_t)q * d.n + s] = FIX_ONE;
+        d.ppr[a] = FIX_ONE;
         z.reserved = FIX_ONE;
         z.dangling_source = 1;
+    } else if (mode == 1) {
+        d.residue[a] = FIX_ONE;
+    } else if (d.binned) {
+        // bucketed push: a frontier entry is (node, residue taken from it); k_pushq_bin of level 0 pops it
+        d.fl[0][(uint64_t)q * d.n] = s;
+        d.inc_tab[0][(uint64_t)q * d.segq_cap] = FIX_ONE;
+        d.fl_count[0][q * CSTRIDE] = 1;
     } else {
-        d.residue[(uint64_t)q * d.n + s] = FIX_ONE;
-        if (mode != 1) {
-            if (d.binned) {
-                d.fl[0][(uint64_t)q * d.n] = s;
-                d.fl_count[0][q * CSTRIDE] = 1;
-            } else {
-                unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
-                d.wl[0][i] = ((uint64_t)q << 32) | s;
-            }
-        }
+        d.residue[a] = FIX_ONE;
+        unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
+        d.wl[0][i] = ((uint64_t)q << 32) | s;
     }
     d.qs[q] = z;
 }
@@ -382,7 +410,7 @@ __global__ void __launch_bounds__(BLOCK) k_push_pop(Dev d, int L) {
             if (lane == 0 && sp) {
                 QState *s = &d.qs[q0];
                 atomicAdd(&s->reserved, (unsigned long long)sr);
-                if (sd) atomicAdd(&s->dang, (unsigned long long)sd);
+                if (sd) atomicAdd(&s->dang[0], (unsigned long long)sd);
                 atomicAdd(&s->pops, (unsigned long long)sp);
                 if (se) atomicAdd(&s->relax, (unsigned long long)se);
                 s->levels = (uint32_t)L + 1;
@@ -390,7 +418,7 @@ __global__ void __launch_bounds__(BLOCK) k_push_pop(Dev d, int L) {
         } else if (act) {
             QState *s = &d.qs[q];
             atomicAdd(&s->reserved, (unsigned long long)res_add);
-            if (dang) atomicAdd(&s->dang, (unsigned long long)dang);
+            if (dang) atomicAdd(&s->dang[0], (unsigned long long)dang);
             atomicAdd(&s->pops, 1ull);
             if (deg) atomicAdd(&s->relax, (unsigned long long)deg);
             s->levels = (uint32_t)L + 1;
@@ -420,9 +448,9 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
         bool cross = false;
         uint64_t item = 0;
         if (q < d.nq) {
-            const uint64_t dm = d.qs[q].dang;
+            const uint64_t dm = d.qs[q].dang[0];
             if (dm) {
-                d.qs[q].dang = 0;
+                d.qs[q].dang[0] = 0;
                 const uint32_t s = (uint32_t)d.src[q];
                 const uint64_t old = atomicAdd((unsigned long long *)&d.residue[(uint64_t)q * d.n + s],
                                                (unsigned long long)dm);
@@ -479,24 +507,30 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // ------------------------------------------------------------------ bucketed push
 // Same level semantics as k_push_pop / k_push_expand, reorganised so that no per-edge global
 // atomic is needed (measured: every global atomic flavour caps at ~23 G/s chip-wide, ~5 G/s
-// with power-law hot targets).  Per level (and per pass of <= 1024 bins on huge graphs):
-//   k_pushq_popbin  frontier (per-slot list) -> reserve, increments binned by target range: per
-//                   2048-edge chunk an LDS histogram, ONE global atomic per (chunk, bin) to
-//                   reserve bucket space, then bin-sorted message stores
+// with power-law hot targets).  A frontier entry is (node, residue): whoever put it there TOOK the
+// residue (the slab word is already 0).  Per level (and per pass of <= 1024 bins on huge graphs):
+//   k_pushq_bin     frontier (per-slot list, node-ordered inside every bin's run) -> the pop arithmetic
+//                   (alpha of the residue to the reserve slab, increment per out-edge) one entry per
+//                   lane, then increments binned by target range: per 2048-edge chunk an LDS
+//                   histogram, ONE global atomic per (chunk, bin) to reserve bucket space, then
+//                   bin-sorted message stores
 //   k_accum<false>  one workgroup per (slot, bin): ds_add_u64 every message into 64 KiB of LDS
 //                   accumulators, then sweep them: one plain RMW per touched node (the
-//                   workgroup owns that residue range), threshold crossing -> next frontier
+//                   workgroup owns that residue range); a node that crosses its threshold has
+//                   its residue line in hand: it is stored as 0 and (node, residue) goes to the
+//                   next frontier at a rank that follows the NODE ORDER, so the next level reads
+//                   rows, reserves and residues almost sequentially and never gathers a residue.
 // Integer adds commute, so the result is bit-identical to the direct path and to the twin.
 
-// grid = (X, nq).  Fused pop + bin: a block takes 256 frontier nodes of a slot, pops them (residue ->
-// reserve, increment; algo.h:983-1002) straight into LDS, then bins their concatenated out-edges in
-// chunks of BIN_EPT * BLOCK: each lane gathers BIN_EPT consecutive edges (all loads issued before any
-// is waited for), an LDS histogram over the target bins gives every message its rank, ONE global
-// atomic per (chunk, bin) reserves bucket space, and the messages are staged bin-sorted in LDS and
-// written out in runs.  No slice list is materialised: a narrow message names the frontier position of
-// its source node (increment table `inc_tab`), a wide one carries the increment.
+// grid = (X, nq).  A block takes 256 frontier entries of a slot, pops them (residue -> reserve, increment;
+// algo.h:983-1002; row start, increment, degree prefix sum into LDS), then bins their concatenated out-edges in chunks of BIN_EPT * BLOCK: each lane gathers
+// BIN_EPT consecutive edges (all loads issued before any is waited for), an LDS histogram over the
+// target bins gives every message its rank, ONE global atomic per (chunk, bin) reserves bucket space,
+// and the messages are staged bin-sorted in LDS and written out in runs.  No slice list is
+// materialised: a narrow message names the frontier position of its source node (increment table
+// `inc_tab`), a wide one carries the increment.
 template <int NB>
-__global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
+__global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const int q = blockIdx.y;
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
@@ -515,67 +549,48 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
     // stage: narrow = message + bucket slot; wide = ONE word per message, local target (13 bits) | source node inside
     // the tile (8) | bin (10) -- 8 KiB instead of 24, which lifts the wide kernel from 3 to 5 workgroups per CU
     __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[WIDE ? 1 : BLOCK * BIN_EPT];
-    const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t *in = d.fl[par] + slab;
-    uint64_t *incs = d.inc_tab + (uint64_t)q * d.segq_cap;
+    uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
     const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
     for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
+    STAMP_DECL
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < count; tbase += gridDim.x * BLOCK) {
-        // ---- pop: one frontier node per lane
+        // ---- one frontier entry per lane
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
-        if (i < count && !first_pass) { // later pass of this level: the node was popped in pass 0
+        uint64_t rsv_old = 0, rsv_add = 0, rsv_at = 0;
+        if (i < count) {
             const uint32_t v = in[i];
+            uint64_t inc = incs[i]; // first pass: the residue taken from v; later passes: its increment
             int64_t beg; uint64_t deg;
             node_row(d, v, beg, deg);
+            if (first_pass) { // pop (algo.h:983-1002): the residue word itself was zeroed when v entered the list
+                rsv_at = slab + v;
+                rsv_old = d.ppr[rsv_at];
+                uint64_t dang;
+                inc = pop_value(d.afix, inc, (uint32_t)deg, rsv_add, dang);
+                incs[i] = inc;
+                acc_res += rsv_add; acc_dang += dang; acc_pops++; acc_relax += deg;
+            }
             if (d.row_split) { // only the part of the (sorted) row whose targets belong to this pass
                 const uint32_t *sp = d.row_split + (uint64_t)v * (d.npass + 1) + d.pass;
                 beg += sp[0];
                 deg = sp[1] - sp[0];
             }
             s_ebeg[threadIdx.x] = beg;
-            s_inc[threadIdx.x] = incs[i];
-            cnt = (uint32_t)deg;
-        } else if (i < count) {
-            const uint32_t v = in[i];
-            const uint64_t a = slab + v;
-            const uint64_t r = d.residue[a];
-            int64_t beg; uint64_t deg;
-            node_row(d, v, beg, deg);
-            const uint64_t reserve_old = d.ppr[a];
-            d.residue[a] = 0;                                 // algo.h:985
-            const uint64_t keep = mulshift62(r, d.afix);      // v_residue * alpha
-            const uint64_t push = r - keep;                   // (1-alpha) * v_residue
-            uint64_t inc = 0, res_add;
-            if (deg == 0) {                                   // algo.h:993-994
-                res_add = keep;
-                acc_dang += push;
-            } else {
-                inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg; // algo.h:1002
-                res_add = keep + (push - inc * deg);          // division remainder stays reserved
-            }
-            d.ppr[a] = reserve_old + res_add;                 // algo.h:986-989 (only this lane owns (q,v))
-            acc_res += res_add;
-            acc_pops++;
-            acc_relax += deg;
-            if (d.row_split) { // pass 0 of several: bin only the head of the sorted row
-                const uint32_t *sp = d.row_split + (uint64_t)v * (d.npass + 1);
-                deg = sp[1]; // sp[0] == 0
-            }
-            s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = inc;
-            incs[i] = inc;
-            cnt = (uint32_t)deg;
+            cnt = inc ? (uint32_t)deg : 0u; // an increment of zero changes nothing: skip the row
         }
         uint32_t total;
         const uint32_t pre = block_excl_scan(cnt, s_w, total);
         s_pref[threadIdx.x] = pre;
         if (threadIdx.x == 0) s_pref[BLOCK] = total;
         __syncthreads();
+        STAMP(0);
         // ---- bin the tile's edges
         for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
@@ -590,7 +605,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < BIN_EPT; k++) { // dangling nodes own no edges: step over them
+            for (int k = 0; k < BIN_EPT; k++) { // entries without edges: step over them
                 const uint32_t e = e0 + k;
                 if (e < total) while (s_pref[lo + 1] <= e) lo++;
                 si[k] = lo;
@@ -607,6 +622,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(w[k] >> BIN_SHIFT) - bin_lo], 1u); // rank inside (chunk, bin)
             }
             __syncthreads();
+            STAMP(1);
             uint32_t staged; // messages of this chunk that belong to the pass's bins
             { // reserve bucket space (ONE global atomic per (chunk, bin)) and lay the bins out in the LDS stage:
               // lane t owns bins t*PER .. t*PER+PER-1
@@ -635,6 +651,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 }
             }
             __syncthreads();
+            STAMP(2);
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
                 if (w[k] != 0xFFFFFFFFu) {
@@ -657,6 +674,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                 }
             }
             __syncthreads();
+            STAMP(3);
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
                 if (WIDE) {
                     const uint32_t e = s_msg[m];
@@ -678,18 +696,20 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
                     if (dst != 0xFFFFFFFFu) d.bk_w[bk0 + dst] = s_msg[m];
                 }
             }
+            STAMP(4);
         }
+        if (rsv_add) d.ppr[rsv_at] = rsv_old + rsv_add; // algo.h:986-989 (only this lane owns (q, v)); its load had the whole tile to arrive
         __syncthreads();
     }
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
-    if (lane == 0 && acc_pops) { // (only the first pass pops)
-        QState *s = &d.qs[q];
-        atomicAdd(&s->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
-        if (acc_dang) atomicAdd(&s->dang, (unsigned long long)acc_dang);
-        atomicAdd(&s->pops, (unsigned long long)acc_pops);
-        if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
-        s->levels = (uint32_t)L + 1;
+    if ((threadIdx.x & 63) == 0 && acc_pops) { // (only the first pass pops)
+        QState *qs = &d.qs[q];
+        atomicAdd(&qs->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
+        if (acc_dang) atomicAdd(&qs->dang[par], (unsigned long long)acc_dang);
+        atomicAdd(&qs->pops, (unsigned long long)acc_pops);
+        if (acc_relax) atomicAdd(&qs->relax, (unsigned long long)acc_relax);
+        qs->levels = (uint32_t)L + 1;
     }
 }
 
@@ -699,7 +719,8 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_popbin(Dev d, int L) {
 // dangling mass -- with workgroup barriers instead of launches and one returning atomic per relaxation (the slot's
 // slabs are touched by this workgroup only; every mutable word is read and written through atomics or cache-bypassing
 // loads, so no stale L1 line is ever observed).  Integer adds commute: same bits as the bucketed levels and the twin.
-// grid = nq, TAIL_THREADS threads.  L0: first level to run; max_levels: stop after that many more (0: until empty).
+// grid = nq, TAIL_THREADS threads.  L0: first level to run (its entries carry their residue, see k_accum);
+// max_levels: stop after that many more (0: until empty).
 constexpr int TAIL_THREADS = 1024;
 __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int max_levels) {
     __shared__ int64_t s_ebeg[TAIL_THREADS];
@@ -712,12 +733,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t src = (uint32_t)d.src[q];
-    uint64_t *incs = d.inc_tab + (uint64_t)q * d.segq_cap;
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
     uint32_t last_level = 0;
     for (int done = 0; max_levels <= 0 || done < max_levels; done++, L++) {
         const int par = L & 1;
+        uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
         if (tid == 0) {
             s_count = __atomic_load_n(&d.fl_count[par][q * CSTRIDE], __ATOMIC_RELAXED);
             s_next = 0;
@@ -727,24 +748,20 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
         const uint32_t count = s_count;
         if (!count) break;
         if (L >= MAX_LEVELS) { if (tid == 0) atomicOr(d.err, ERR_WL_OVERFLOW); break; }
-        last_level = (uint32_t)L + 1;
         const uint32_t *in = d.fl[par] + slab;
         uint32_t *out = d.fl[par ^ 1] + slab;
-        // ---- all pops of the level (algo.h:983-1002)
+        // ---- all pops of the level (algo.h:983-1002).  The entries of level L0 carry the residue already taken from
+        // their nodes (see k_accum); later levels are collected by this kernel and take it here.
+        last_level = (uint32_t)L + 1;
         for (uint32_t i = tid; i < count; i += TAIL_THREADS) {
             const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
             const uint64_t a = slab + v;
-            const uint64_t r = atomicExch((unsigned long long *)&d.residue[a], 0ull);   // algo.h:984-985
-            int64_t beg; uint64_t deg;
-            node_row(d, v, beg, deg);
-            const uint64_t keep = mulshift62(r, d.afix);
-            const uint64_t push = r - keep;
-            uint64_t inc = 0, res_add;
-            if (deg == 0) { res_add = keep; atomicAdd(&s_dang, (unsigned long long)push); } // algo.h:993-994
-            else {
-                inc = deg < (1ull << 32) ? div_u64_u32(push, (uint32_t)deg) : push / deg;   // algo.h:1002
-                res_add = keep + (push - inc * deg);
-            }
+            const uint64_t r = done ? atomicExch((unsigned long long *)&d.residue[a], 0ull)      // algo.h:984-985
+                                    : __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
+            const uint32_t deg = d.deg[v];
+            uint64_t res_add, dang;
+            const uint64_t inc = pop_value(d.afix, r, deg, res_add, dang);                  // algo.h:986-1002
+            if (dang) atomicAdd(&s_dang, (unsigned long long)dang);                         // algo.h:993-994
             atomicAdd((unsigned long long *)&d.ppr[a], (unsigned long long)res_add);        // algo.h:986-989
             incs[i] = inc;
             acc_res += res_add;
@@ -826,30 +843,47 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
 
 // grid = (bins of the pass, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
 // to the ppr slab and there is no threshold / frontier.
+//
+// Push form (TO_PPR = false), level L: after the sweep has added the level's increments to the residue range this
+// workgroup owns, every node that crossed its threshold (algo.h:1012) enters the frontier of level L + 1 right here
+// (d.pop_next = 0 on the last level of a capped run leaves it alone): its residue is in registers, so the slab word is
+// stored as 0 (algo.h:984-985) and (node, residue) is appended at a rank that follows the NODE ORDER inside the bin.
+// The bin kernel of the next level finishes the pop with dense lanes and never gathers a residue.
 template <bool TO_PPR>
 __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint64_t acc[BIN_SIZE];
+    constexpr int NW = ACC_THREADS / 64;
+    constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
+    __shared__ uint32_t s_rank[TO_PPR ? 1 : SWEEP * NW + 1];
+    __shared__ uint32_t s_gbase;
+    __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
+    __shared__ uint32_t s_nlist;
     const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
     const int b = d.bin_lo + lb;
+    const int par = L & 1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t bi = (uint32_t)q * d.pbins + lb;
     uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
     if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess is in the overflow list (push) / went by direct atomics (walks)
     const uint32_t s = (uint32_t)d.src[q];
-    const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang : 0; // algo.h:994
+    const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
     uint64_t *target = TO_PPR ? d.ppr : d.residue;
+    if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         d.bk_count[(uint64_t)bi * CSTRIDE] = 0;
-        if (dm) d.qs[q].dang = 0;
+        if (dm) d.qs[q].dang[par] = 0;
     }
-    uint32_t ovn = TO_PPR ? 0 : d.ov_count[L & 1][q * CSTRIDE];
+    uint32_t ovn = TO_PPR ? 0 : d.ov_count[par][q * CSTRIDE];
     if (ovn > d.ov_cap) ovn = d.ov_cap;
     if (cnt == 0 && dm == 0 && ovn == 0) return;
-    uint32_t *fl_next = d.fl[(L & 1) ^ 1] + slab;
-    uint32_t *flc_next = &d.fl_count[(L & 1) ^ 1][q * CSTRIDE];
+    uint32_t *fl_next = d.fl[par ^ 1] + slab;
+    uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
+    uint32_t *flc_next = &d.fl_count[par ^ 1][q * CSTRIDE];
     const uint64_t bk0 = (uint64_t)bi * d.bk_cap;
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
+    const uint64_t *itab = TO_PPR ? nullptr : d.inc_tab[par] + (uint64_t)q * d.segq_cap;
     if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
         // node range and the level's pops are done, so nothing else touches these words)
@@ -869,7 +903,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 else if (TO_PPR) {}
                 else if (d.wide) { inc = d.bk_inc[bk0 + i]; w = node0 + w; }
                 else {
-                    inc = d.inc_tab[(uint64_t)q * d.segq_cap + (w & ((1u << SEG_BITS) - 1))];
+                    inc = itab[w & ((1u << SEG_BITS) - 1)];
                     w = node0 + (w >> SEG_BITS);
                 }
             } else if (i == cnt && dm) { w = s; inc = dm; }
@@ -877,22 +911,43 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
                 if (!TO_PPR) {
                     const uint64_t thr = node_thr(d.t1, d.deg[w]);
-                    cross = old < thr && old + inc >= thr;
+                    cross = old < thr && old + inc >= thr; // increments are positive: exactly one add crosses
                 }
             }
-            if (!TO_PPR && i0 + (threadIdx.x & ~63u) < total) // whole waves only
-                wave_append32(cross, w, fl_next, flc_next, (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
+            if (!TO_PPR) {
+                const unsigned long long mask = __ballot(cross);
+                if (mask) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nlist, (uint32_t)__popcll(mask));
+                    base = __shfl(base, 0);
+                    if (cross) s_list[base + __popcll(mask & ((1ull << lane) - 1))] = w; // <= tiny_max + 1 <= 1024 entries
+                }
+            }
+        }
+        if (TO_PPR || !d.pop_next) return;
+        __syncthreads(); // every add of this bucket has returned: the crossing nodes' residues are final
+        const uint32_t nl = s_nlist;
+        if (!nl) return;
+        if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, nl);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nl; i += ACC_THREADS) {
+            const uint32_t w = s_list[i];
+            const uint64_t r = atomicExch((unsigned long long *)&d.residue[slab + w], 0ull); // algo.h:984-985
+            const uint32_t pos = s_gbase + i;
+            if (pos < (uint32_t)d.n) { fl_next[pos] = w; inc_next[pos] = r; }
+            else atomicOr(d.err, ERR_WL_OVERFLOW);
         }
         return;
-    }
+    } else {
+    STAMP_DECL
     for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
     __syncthreads();
+    STAMP(16);
     // messages: ACC_UNROLL per lane and iteration, all loads BRANCH-FREE (clamped index, masked afterwards).
     // With an `if (i < cnt)` around each load hipcc puts every dependent increment gather behind its own
     // s_waitcnt vmcnt(0): eight serialized round trips per iteration instead of two.
     constexpr int ACC_UNROLL = 8;
     const bool gather = !TO_PPR && !d.wide;
-    const uint64_t *itab = d.inc_tab + (uint64_t)q * d.segq_cap;
     const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
     for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
         uint32_t mw[ACC_UNROLL];
@@ -923,60 +978,81 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
             atomicAdd((unsigned long long *)&acc[w & (BIN_SIZE - 1)], (unsigned long long)d.ov_inc[(uint64_t)q * d.ov_cap + i]);
     }
     __syncthreads();
+    STAMP(17);
     // sweep: consecutive lanes -> consecutive nodes; all loads of a lane's 16 nodes in flight together
-    constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
-    uint64_t v[SWEEP], old[SWEEP];
-    uint32_t dg[SWEEP];
-#pragma unroll
-    for (int k = 0; k < SWEEP; k++) v[k] = acc[k * ACC_THREADS + threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < SWEEP; k++) {
-        old[k] = 0; dg[k] = 0;
-        if (v[k]) {
-            const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
-            old[k] = target[slab + node];
-            if (!TO_PPR) dg[k] = d.deg[node];
-        }
-    }
     uint32_t crossmask = 0;
+    {
+        uint64_t v[SWEEP], old[SWEEP];
+        uint32_t dg[SWEEP];
 #pragma unroll
-    for (int k = 0; k < SWEEP; k++) {
-        const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
-        if (v[k]) {
-            target[slab + node] = old[k] + v[k]; // this workgroup owns [node0, node0 + BIN_SIZE) of slot q
-            if (!TO_PPR) {
-                const uint64_t thr = node_thr(d.t1, dg[k]);
-                if (old[k] < thr && old[k] + v[k] >= thr) crossmask |= 1u << k; // algo.h:1012
+        for (int k = 0; k < SWEEP; k++) v[k] = acc[k * ACC_THREADS + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < SWEEP; k++) {
+            old[k] = 0; dg[k] = 0;
+            if (v[k]) {
+                const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+                old[k] = target[slab + node];
+                if (!TO_PPR) dg[k] = d.deg[node];
+            }
+        }
+        const bool pop = !TO_PPR && d.pop_next;
+#pragma unroll
+        for (int k = 0; k < SWEEP; k++) {
+            const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+            if (v[k]) {
+                const uint64_t nw = old[k] + v[k];
+                bool cross = false;
+                if (!TO_PPR) {
+                    const uint64_t thr = node_thr(d.t1, dg[k]);
+                    cross = pop && old[k] < thr && nw >= thr; // algo.h:1012
+                }
+                // this workgroup owns [node0, node0 + BIN_SIZE) of slot q; a crossing node gives its residue to the
+                // frontier entry written below (algo.h:984-985)
+                target[slab + node] = cross ? 0 : nw;
+                if (cross) { crossmask |= 1u << k; acc[k * ACC_THREADS + threadIdx.x] = nw; } // own LDS word: no barrier needed
             }
         }
     }
+    STAMP(18);
     if (TO_PPR) return;
-    // next frontier: ONE global atomic per workgroup (the per-slot counter is a hot address)
-    __shared__ uint32_t s_wtot[ACC_THREADS / 64];
-    __shared__ uint32_t s_gbase;
-    uint32_t wtot;
-    const uint32_t mine = __popc(crossmask);
-    const uint32_t wpre = wave_excl_scan(mine, wtot);
-    if ((threadIdx.x & 63) == 0) s_wtot[threadIdx.x >> 6] = wtot;
-    __syncthreads();
-    uint32_t before = 0, total = 0;
+    // ---- rank of every crossing node in node order: node = node0 + k * ACC_THREADS + thread, so order by (k, wave, lane)
+    constexpr int CELLS = SWEEP * NW;
+    static_assert(CELLS <= 128, "the scan below handles two (k, wave) cells per lane of one wave");
 #pragma unroll
-    for (int w = 0; w < ACC_THREADS / 64; w++) {
-        const uint32_t c = s_wtot[w];
-        if (w < (int)(threadIdx.x >> 6)) before += c;
-        total += c;
+    for (int k = 0; k < SWEEP; k++) {
+        const unsigned long long m = __ballot((crossmask >> k) & 1u);
+        if (lane == 0) s_rank[k * NW + wid] = (uint32_t)__popcll(m);
     }
-    if (!total) return;
-    if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, total);
     __syncthreads();
-    uint32_t pos = s_gbase + before + wpre;
-#pragma unroll
-    for (int k = 0; k < SWEEP; k++)
-        if (crossmask & (1u << k)) {
-            if (pos < (uint32_t)d.n) fl_next[pos] = node0 + k * ACC_THREADS + threadIdx.x;
-            else atomicOr(d.err, ERR_WL_OVERFLOW);
-            pos++;
+    if (wid == 0) { // exclusive scan of the (k, wave) counts by one wave, two per lane
+        const uint32_t c0 = 2 * lane < CELLS ? s_rank[2 * lane] : 0, c1 = 2 * lane + 1 < CELLS ? s_rank[2 * lane + 1] : 0;
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(c0 + c1, tot);
+        if (2 * lane < CELLS) s_rank[2 * lane] = ex;
+        if (2 * lane + 1 < CELLS) s_rank[2 * lane + 1] = ex + c0;
+        if (lane == 0) {
+            s_rank[CELLS] = tot;
+            s_gbase = tot ? atomicAdd(flc_next, tot) : 0u; // ONE global atomic per workgroup (the per-slot counter is a hot address)
         }
+    }
+    __syncthreads();
+    STAMP(19);
+    if (!s_rank[CELLS]) return;
+    const uint32_t gbase = s_gbase;
+#pragma unroll
+    for (int k = 0; k < SWEEP; k++) {
+        const bool c = (crossmask >> k) & 1u;
+        const unsigned long long m = __ballot(c);
+        if (c) {
+            const uint32_t pos = gbase + s_rank[k * NW + wid] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (pos < (uint32_t)d.n) {
+                fl_next[pos] = node0 + k * ACC_THREADS + threadIdx.x;
+                inc_next[pos] = acc[k * ACC_THREADS + threadIdx.x];
+            } else atomicOr(d.err, ERR_WL_OVERFLOW);
+        }
+    }
+    STAMP(20);
+    }
 }
 
 // ------------------------------------------------------------------ walk allocation
@@ -1080,23 +1156,39 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
 
 // ------------------------------------------------------------------ top-k support
 // Round frontier of the incremental push (algo.h:1020-1093): every node of an active slot
-// whose residue is at/over this round's threshold.  grid = (chunks, nq).
+// whose residue is at/over this round's threshold.  Bucketed push: a frontier entry is (node, residue taken from it),
+// see k_accum.  grid = (chunks, nq).
 __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *active) {
     const int q = blockIdx.y;
     if (!active[q]) return;
+    const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
     for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
         const uint32_t v = c * BLOCK + threadIdx.x;
         bool in = false;
+        uint64_t r = 0;
+        uint32_t dg = 0;
         if (v < (uint32_t)d.n) {
-            const uint64_t r = d.residue[slab + v];
-            in = r && r >= node_thr(d.t1, d.deg[v]);
+            r = d.residue[slab + v];
+            dg = d.deg[v];
+            in = r && r >= node_thr(d.t1, dg);
         }
-        if (d.binned)
-            wave_append32(in, v, d.fl[0] + slab, &d.fl_count[0][q * CSTRIDE], (uint32_t)d.n, d.err, ERR_WL_OVERFLOW);
-        else
+        if (!d.binned) {
             wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
+            continue;
+        }
+        const unsigned long long mask = __ballot(in);
+        if (!mask) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&d.fl_count[0][q * CSTRIDE], (uint32_t)__popcll(mask));
+        base = __shfl(base, 0);
+        if (in) {
+            d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
+            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            if (pos < (uint32_t)d.n) { d.fl[0][slab + pos] = v; d.inc_tab[0][(uint64_t)q * d.segq_cap + pos] = r; }
+            else atomicOr(d.err, ERR_WL_OVERFLOW);
+        }
     }
 }
 

@@ -173,6 +173,9 @@ int fora_hip_walks(fora_ctx *ctx, uint32_t stream, uint32_t round, int no_zero_h
 /* ---- measurement ----------------------------------------------------------- */
 int fora_hip_reset_timing(fora_ctx *ctx);
 int fora_hip_get_timing(fora_ctx *ctx, fora_timing *out);
+/* diagnostic builds (-DFORA_STAMPS) only: shader-clock cycles per kernel phase summed over workgroups since the last
+ * fora_hip_reset_timing; [0..15] k_pushq_bin, [16..31] k_accum.  All zero in a product build. */
+int fora_hip_get_stamps(fora_ctx *ctx, uint64_t *out32);
 
 #ifdef __cplusplus
 }
