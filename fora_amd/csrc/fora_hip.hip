@@ -910,7 +910,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     if (!c) return FORA_E_ARG;
     if (n <= 0 || !row_ptr || row_ptr[0] != 0) return fail(c, FORA_E_ARG, "bad graph");
     const int64_t nnz = row_ptr[n];
-    if (nnz < 0 || (nnz && !col) || nnz >= (1ll << 40)) return fail(c, FORA_E_ARG, "bad graph (nnz)");
+    if (nnz < 0 || (nnz && !col) || nnz >= (1ll << 32)) return fail(c, FORA_E_ARG, "bad graph (nnz): at most 2^32 - 1 edges");
     for (int32_t v = 0; v < n; v++)
         if (row_ptr[v + 1] < row_ptr[v]) return fail(c, FORA_E_ARG, "row_ptr not monotone");
     for (int64_t e = 0; e < nnz; e++)

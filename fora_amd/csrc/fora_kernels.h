@@ -152,11 +152,13 @@ struct Dev {
 // ------------------------------------------------------------------ helpers
 // Diagnostic build: thread 0 of a workgroup adds the shader-clock cycles since the previous stamp to d.stamps[slot].
 #ifdef FORA_STAMPS
-#define STAMP_DECL long long st_t_ = clock64();
-#define STAMP(slot) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(&d.stamps[slot], (unsigned long long)(n_ - st_t_)); st_t_ = n_; } } while (0)
+#define STAMP_DECL long long st_t_ = clock64(); unsigned long long st_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)st_a_;
+#define STAMP(slot) do { const long long n_ = clock64(); st_a_[(slot) & 7] += (unsigned long long)(n_ - st_t_); st_t_ = n_; } while (0)
+#define STAMP_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (st_a_[i_]) atomicAdd(&d.stamps[(base) + i_], st_a_[i_]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(slot) do {} while (0)
+#define STAMP_FLUSH(base) do {} while (0)
 #endif
 __device__ __forceinline__ uint64_t mulshift62(uint64_t r, uint64_t a) {
     return (__umul64hi(r, a) << 2) | ((r * a) >> 62);
@@ -201,6 +203,12 @@ __device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg,
     beg = (int64_t)(ri >> 24);
     deg = ri & DEG_SAT;
     if (deg == DEG_SAT) deg = (uint64_t)(d.row_ptr[v + 1] - beg);
+}
+
+// exact out-degree from a rowinfo word (the 24-bit field saturates on hubs)
+__device__ __forceinline__ uint32_t ri_deg(const Dev &d, uint64_t ri, uint32_t v) {
+    const uint32_t dg = (uint32_t)ri & DEG_SAT;
+    return dg == DEG_SAT ? (uint32_t)(d.row_ptr[v + 1] - (int64_t)(ri >> 24)) : dg;
 }
 
 struct __attribute__((packed, aligned(4))) U32Pair { uint32_t a, b; }; // dword-aligned pair: one dwordx2 load
@@ -522,13 +530,15 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 //                   rows, reserves and residues almost sequentially and never gathers a residue.
 // Integer adds commute, so the result is bit-identical to the direct path and to the twin.
 
-// grid = (X, nq).  A block takes 256 frontier entries of a slot, pops them (residue -> reserve, increment;
-// algo.h:983-1002; row start, increment, degree prefix sum into LDS), then bins their concatenated out-edges in chunks of BIN_EPT * BLOCK: each lane gathers
-// BIN_EPT consecutive edges (all loads issued before any is waited for), an LDS histogram over the
-// target bins gives every message its rank, ONE global atomic per (chunk, bin) reserves bucket space,
-// and the messages are staged bin-sorted in LDS and written out in runs.  No slice list is
-// materialised: a narrow message names the frontier position of its source node (increment table
-// `inc_tab`), a wide one carries the increment.
+// grid = (X, nq).  A block takes 256 frontier entries (node, residue) of a slot and pops them (residue -> reserve, increment;
+// algo.h:983-1002; row start, increment, degree prefix sum into LDS).  Then it bins their concatenated out-edges in
+// chunks of BIN_EPT * BLOCK: each lane gathers BIN_EPT consecutive edges (all loads issued before any is waited
+// for), an LDS histogram over the target bins gives every message its rank, ONE global atomic per (chunk, bin)
+// reserves bucket space -- in flight while the messages are staged bin-sorted in LDS -- and the stage is written out
+// in runs.  No slice list is materialised: a narrow message names the frontier position of its source node
+// (increment table `inc_tab`), a wide one carries the increment.  Measured and dropped: gathering with
+// consecutive lanes on consecutive edges through an LDS address table, carrying rowinfo in the frontier entry, and
+// loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
 template <int NB>
 __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const int q = blockIdx.y;
@@ -541,17 +551,21 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     }
     if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
+    constexpr uint32_t CHUNK = BLOCK * BIN_EPT;
     __shared__ int64_t s_ebeg[BLOCK];
     __shared__ uint64_t s_inc[BLOCK];
     __shared__ uint32_t s_pref[BLOCK + 1];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    // stage: narrow = message + bucket slot; wide = ONE word per message, local target (13 bits) | source node inside
-    // the tile (8) | bin (10) -- 8 KiB instead of 24, which lifts the wide kernel from 3 to 5 workgroups per CU
-    __shared__ uint32_t s_msg[BLOCK * BIN_EPT], s_dst[WIDE ? 1 : BLOCK * BIN_EPT];
+    // stage: ONE word per message.  narrow: (local target << SEG_BITS) | frontier position, its bin in s_bin;
+    // wide: local target (13 bits) | source entry inside the tile (8) | bin (10)
+    __shared__ uint32_t s_msg[CHUNK];
+    __shared__ uint8_t s_bin[WIDE ? 1 : CHUNK]; // narrow: bin of the staged message
+    const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
+    const uint64_t fbase = (uint64_t)q * d.segq_cap;
     const uint32_t *in = d.fl[par] + slab;
-    uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
+    uint64_t *incs = d.inc_tab[par] + fbase;
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
     const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
@@ -562,18 +576,18 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
         // ---- one frontier entry per lane
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
-        uint64_t rsv_old = 0, rsv_add = 0, rsv_at = 0;
         if (i < count) {
             const uint32_t v = in[i];
             uint64_t inc = incs[i]; // first pass: the residue taken from v; later passes: its increment
-            int64_t beg; uint64_t deg;
-            node_row(d, v, beg, deg);
+            const uint64_t ri = d.rowinfo[v];
+            int64_t beg = (int64_t)(ri >> 24);
+            uint32_t deg = ri_deg(d, ri, v);
             if (first_pass) { // pop (algo.h:983-1002): the residue word itself was zeroed when v entered the list
-                rsv_at = slab + v;
-                rsv_old = d.ppr[rsv_at];
-                uint64_t dang;
-                inc = pop_value(d.afix, inc, (uint32_t)deg, rsv_add, dang);
+                const uint64_t rsv_old = d.ppr[slab + v];
+                uint64_t rsv_add, dang;
+                inc = pop_value(d.afix, inc, deg, rsv_add, dang);
                 incs[i] = inc;
+                if (rsv_add) d.ppr[slab + v] = rsv_old + rsv_add; // algo.h:986-989 (only this lane owns (q, v))
                 acc_res += rsv_add; acc_dang += dang; acc_pops++; acc_relax += deg;
             }
             if (d.row_split) { // only the part of the (sorted) row whose targets belong to this pass
@@ -583,7 +597,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             }
             s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = inc;
-            cnt = inc ? (uint32_t)deg : 0u; // an increment of zero changes nothing: skip the row
+            cnt = inc ? deg : 0u; // an increment of zero changes nothing: skip the row
         }
         uint32_t total;
         const uint32_t pre = block_excl_scan(cnt, s_w, total);
@@ -592,9 +606,9 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
         __syncthreads();
         STAMP(0);
         // ---- bin the tile's edges
-        for (uint32_t cb = 0; cb < total; cb += BLOCK * BIN_EPT) {
+        for (uint32_t cb = 0; cb < total; cb += CHUNK) {
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
-            const uint32_t e0 = cb + threadIdx.x * BIN_EPT;
+            const uint32_t e0 = cb + threadIdx.x * BIN_EPT; // lane t takes 8 consecutive edges: ONE binary search for the source entry
             uint32_t lo = 0;
             if (e0 < total) {
                 uint32_t hi = BLOCK;
@@ -624,10 +638,12 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             __syncthreads();
             STAMP(1);
             uint32_t staged; // messages of this chunk that belong to the pass's bins
-            { // reserve bucket space (ONE global atomic per (chunk, bin)) and lay the bins out in the LDS stage:
-              // lane t owns bins t*PER .. t*PER+PER-1
-                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
-                uint32_t c[PER], mine = 0;
+            // reserve bucket space (ONE global atomic per (chunk, bin), left in flight) and lay the bins out in the
+            // LDS stage: lane t owns bins t*PER .. t*PER+PER-1
+            constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+            uint32_t c[PER], gb[PER];
+            {
+                uint32_t mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
@@ -640,11 +656,12 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
+                    gb[j] = 0;
                     if (b < (uint32_t)NB) {
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) {
-                            s_base[b] = atomicAdd(&bkc[b * CSTRIDE], c[j]);
+                            gb[j] = atomicAdd(&bkc[b * CSTRIDE], c[j]);
                             s_cnt[b] = 0;
                         }
                     }
@@ -657,53 +674,43 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                 if (w[k] != 0xFFFFFFFFu) {
                     const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    if (WIDE) {
-                        s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (si[k] << BIN_SHIFT) | (b << (BIN_SHIFT + 8));
-                    } else {
-                        const uint32_t pos = s_base[b] + rank[k];
-                        s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + si[k]);
-                        s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
-                        if (pos >= d.bk_cap) { // bucket full: park the increment in the slot's overflow list
-                            const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
-                            if (oi < d.ov_cap) {
-                                d.ov_w[(uint64_t)q * d.ov_cap + oi] = w[k];
-                                d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[si[k]];
-                            } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
-                        }
-                    }
+                    const uint32_t own = si[k];
+                    if (WIDE) s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) | (b << (BIN_SHIFT + 8));
+                    else { s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own); s_bin[sp] = (uint8_t)b; }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < PER; j++) // the reservations have had the staging to come back
+                if (c[j]) s_base[threadIdx.x * PER + j] = gb[j];
             __syncthreads();
             STAMP(3);
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
-                if (WIDE) {
-                    const uint32_t e = s_msg[m];
-                    const uint32_t b = e >> (BIN_SHIFT + 8), sidx = (e >> BIN_SHIFT) & 255u, local = e & (BIN_SIZE - 1);
-                    const uint32_t pos = s_base[b] + (m - s_lofs[b]);
-                    if (pos < d.bk_cap) {
-                        const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
-                        d.bk_w[at] = local;
-                        d.bk_inc[at] = s_inc[sidx];
-                    } else { // bucket full: park the increment in the slot's overflow list
-                        const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
-                        if (oi < d.ov_cap) {
-                            d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
-                            d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
-                        } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
-                    }
-                } else {
-                    const uint32_t dst = s_dst[m];
-                    if (dst != 0xFFFFFFFFu) d.bk_w[bk0 + dst] = s_msg[m];
+                const uint32_t e = s_msg[m];
+                uint32_t b, sidx, local;
+                if (WIDE) { b = e >> (BIN_SHIFT + 8); sidx = (e >> BIN_SHIFT) & 255u; local = e & (BIN_SIZE - 1); }
+                else { b = s_bin[m]; sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
+                const uint32_t pos = s_base[b] + (m - s_lofs[b]);
+                if (pos < d.bk_cap) {
+                    const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
+                    if (WIDE) { d.bk_w[at] = local; d.bk_inc[at] = s_inc[sidx]; }
+                    else d.bk_w[at] = e;
+                } else { // bucket full: park the increment in the slot's overflow list
+                    const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
+                    if (oi < d.ov_cap) {
+                        d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
+                        d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
+                    } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
                 }
             }
             STAMP(4);
         }
-        if (rsv_add) d.ppr[rsv_at] = rsv_old + rsv_add; // algo.h:986-989 (only this lane owns (q, v)); its load had the whole tile to arrive
         __syncthreads();
+        STAMP(5);
     }
+    STAMP_FLUSH(0);
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
-    if ((threadIdx.x & 63) == 0 && acc_pops) { // (only the first pass pops)
+    if (lane == 0 && acc_pops) { // (only the first pass pops)
         QState *qs = &d.qs[q];
         atomicAdd(&qs->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
         if (acc_dang) atomicAdd(&qs->dang[par], (unsigned long long)acc_dang);
@@ -940,32 +947,42 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         return;
     } else {
     STAMP_DECL
-    for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
-    __syncthreads();
-    STAMP(16);
     // messages: ACC_UNROLL per lane and iteration, all loads BRANCH-FREE (clamped index, masked afterwards).
     // With an `if (i < cnt)` around each load hipcc puts every dependent increment gather behind its own
-    // s_waitcnt vmcnt(0): eight serialized round trips per iteration instead of two.
+    // s_waitcnt vmcnt(0): eight serialized round trips per iteration instead of two.  The message words of an
+    // iteration are requested one iteration ahead; the first ones travel while the accumulators are zeroed.
     constexpr int ACC_UNROLL = 8;
     const bool gather = !TO_PPR && !d.wide;
     const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
-    for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
-        uint32_t mw[ACC_UNROLL];
-        uint64_t mi[ACC_UNROLL];
+    uint32_t mw[ACC_UNROLL];
 #pragma unroll
-        for (int k = 0; k < ACC_UNROLL; k++) {
-            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
-        }
+    for (int k = 0; k < ACC_UNROLL; k++) {
+        const uint32_t i = k * ACC_THREADS + threadIdx.x;
+        mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
+    }
+    for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
+    __syncthreads();
+    STAMP(16);
+    for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
+        uint64_t mi[ACC_UNROLL];
+        uint32_t lc[ACC_UNROLL];
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
             mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[bk0 + (i < cnt ? i : 0)]);
+            lc[k] = gather ? mw[k] >> SEG_BITS : mw[k];
+        }
+        if (i0 + ACC_THREADS * ACC_UNROLL < cnt) {
+#pragma unroll
+            for (int k = 0; k < ACC_UNROLL; k++) {
+                const uint32_t i = i0 + (ACC_UNROLL + k) * ACC_THREADS + threadIdx.x;
+                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < ACC_UNROLL; k++) {
             const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
+            uint32_t local = lc[k];
             uint64_t inc = mi[k];
             if (packed) { local = (uint32_t)inc; inc >>= WPACK_SHIFT; }
             if (i < cnt && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
@@ -1014,7 +1031,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         }
     }
     STAMP(18);
-    if (TO_PPR) return;
+    if (TO_PPR) { STAMP_FLUSH(16); return; }
     // ---- rank of every crossing node in node order: node = node0 + k * ACC_THREADS + thread, so order by (k, wave, lane)
     constexpr int CELLS = SWEEP * NW;
     static_assert(CELLS <= 128, "the scan below handles two (k, wave) cells per lane of one wave");
@@ -1037,7 +1054,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     }
     __syncthreads();
     STAMP(19);
-    if (!s_rank[CELLS]) return;
+    if (!s_rank[CELLS]) { STAMP_FLUSH(16); return; }
     const uint32_t gbase = s_gbase;
 #pragma unroll
     for (int k = 0; k < SWEEP; k++) {
@@ -1052,6 +1069,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         }
     }
     STAMP(20);
+    STAMP_FLUSH(16);
     }
 }
 
