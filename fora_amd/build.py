@@ -56,6 +56,16 @@ def build_cli(force=False):
     return CLI
 
 
+def build_tools(force=False):
+    """Test / bench tooling: the HIP R-MAT generator (tools/rmat_gen.hip)."""
+    src = os.path.join(ROOT, "tools", "rmat_gen.hip")
+    lib = os.path.join(ROOT, "tools", "librmat_gen.so")
+    if not force and _newer(lib, [src]):
+        return lib
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib, src], check=True)
+    return lib
+
+
 def build_oracle():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     return os.path.join(ROOT, "oracle", "libfora_oracle.so")
@@ -64,6 +74,7 @@ def build_oracle():
 def build_all(force=False):
     build_hip(force)
     build_cli(force)
+    build_tools(force)
     build_oracle()
 
 

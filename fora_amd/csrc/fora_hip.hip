@@ -25,8 +25,46 @@ struct EvPair {
 
 } // namespace
 
+// Knobs of the engine.  Read ONCE per context (fora_hip_create: environment FORA_HIP_<NAME>, upper case) and changed
+// afterwards only through fora_hip_set_option; nothing on a query path calls getenv.
+struct Tunables {
+    int64_t direct = 0;          // 1: the one-atomic-per-edge push (test reference)
+    int64_t force_wide = 0;      // 1: wide bucket layout on small graphs too (tests)
+    int64_t pass_bins = MAX_BINS_WIDE; // bins handled per pass in the wide layout
+    int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
+    int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
+    int64_t bkcap = 0;           // bucket capacity in messages (0: default per layout)
+    int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
+    int64_t tiny = 512;          // k_accum: buckets up to this many messages go by direct atomics
+    int64_t xb = 0, ax = 0, wx = 0; // workgroups per slot: bin kernel / slab sweeps / walks (0: from the slot count)
+    int64_t tail = 1024;         // frontier size from which k_push_tail takes over (0: never)
+    int64_t tail_always = 0;     // 1: do not wait for the frontier to have been large first (tests)
+    int64_t select_compact = -1; // top-k select over compacted non-zeros: -1 by graph size, 0 never, 1 always
+    int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
+    int64_t profile = 1;         // 0: no HIP event pairs around the launches
+    int64_t grid = 2048;         // workgroups of the direct-path kernels
+};
+static const struct { const char *name; int64_t Tunables::*field; bool layout; } OPTIONS[] = {
+    {"direct", &Tunables::direct, true}, {"force_wide", &Tunables::force_wide, true}, {"pass_bins", &Tunables::pass_bins, true},
+    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"bkcap", &Tunables::bkcap, true},
+    {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
+    {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false},
+    {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
+};
+static Tunables tunables_from_env() {
+    Tunables t;
+    for (const auto &o : OPTIONS) {
+        std::string env = "FORA_HIP_";
+        for (const char *p = o.name; *p; p++) env += (char)toupper((unsigned char)*p);
+        if (const char *e = getenv(env.c_str())) if (*e) t.*(o.field) = atoll(e);
+    }
+    return t;
+}
+
 struct fora_ctx {
     int device = 0;
+    Tunables opt_;
     hipStream_t stream = nullptr;
     std::string err;
     hipDeviceProp_t prop{};
@@ -178,11 +216,11 @@ constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
 static uint32_t slab_grid_x(const fora_ctx *c, int nq) {
     const int64_t nchunk = ((int64_t)c->n + BLOCK - 1) / BLOCK;
     int64_t x = std::min<int64_t>(1024, std::max<int64_t>(16, 32768 / std::max(1, nq)));
-    if (const char *e = getenv("FORA_HIP_AX")) if (atoi(e) > 0) x = atoi(e);
+    if (c->opt_.ax > 0) x = c->opt_.ax;
     return (uint32_t)std::max<int64_t>(1, std::min(x, nchunk));
 }
-static unsigned walk_grid_x(int nq) {
-    if (const char *e = getenv("FORA_HIP_WX")) if (atoi(e) > 0) return (unsigned)atoi(e);
+static unsigned walk_grid_x(const fora_ctx *c, int nq) {
+    if (c->opt_.wx > 0) return (unsigned)c->opt_.wx;
     // ~24 k workgroups per launch (1280 are resident): ws at 1000 slots, blocks per slot 4 -> 552 ms, 8 -> 509,
     // 16 -> 493, 24 -> 489, 32 -> 495 per 3000 queries
     return (unsigned)std::min(2048, std::max(16, 24576 / std::max(1, nq)));
@@ -191,31 +229,22 @@ static unsigned walk_grid_x(int nq) {
 constexpr int SPEC = 3;          // levels launched ahead of the frontier-size readback
 constexpr int FLC_RING = SPEC + 2;
 
-static bool want_binned(const fora_ctx *c) {
-    const char *e = getenv("FORA_HIP_DIRECT"); // tests: the one-atomic-per-edge path
-    (void)c;
-    return !(e && e[0] == '1');
-}
+static bool want_binned(const fora_ctx *c) { return c->opt_.direct != 1; } // direct: the one-atomic-per-edge path (tests)
 // bins handled per pass in the wide layout (graphs with more bins run several bin/accum passes per level)
-static int want_pass_bins() {
-    const char *e = getenv("FORA_HIP_PASS_BINS");
-    if (e && atoi(e) > 0) return std::min(atoi(e), (int)MAX_BINS_WIDE);
-    return MAX_BINS_WIDE;
+static int want_pass_bins(const fora_ctx *c) {
+    return c->opt_.pass_bins > 0 ? (int)std::min<int64_t>(c->opt_.pass_bins, MAX_BINS_WIDE) : (int)MAX_BINS_WIDE;
 }
 // narrow layout: <= MAX_BINS bins and the slice index fits the 4-byte push message
 static bool want_wide(const fora_ctx *c) {
-    const char *e = getenv("FORA_HIP_FORCE_WIDE"); // tests: exercise the wide layout on small graphs
-    if (e && e[0] == '1') return true;
+    if (c->opt_.force_wide == 1) return true; // tests: exercise the wide layout on small graphs
     return !((uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && (uint64_t)c->n <= (1ull << SEG_BITS));
 }
-static uint32_t want_bk_cap() {
-    const char *e = getenv("FORA_HIP_BKCAP");
-    if (e && atoi(e) > 0) return (uint32_t)atoi(e);
+static uint32_t want_bk_cap(const fora_ctx *c) {
+    if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
     return 163840; // walk results: ~omega*rsum/nbins per bucket (ws: ~110 k)
 }
-static uint32_t want_bk_cap_wide() { // push messages only (walk results go by direct atomics in the wide layout)
-    const char *e = getenv("FORA_HIP_BKCAP");
-    if (e && atoi(e) > 0) return (uint32_t)atoi(e);
+static uint32_t want_bk_cap_wide(const fora_ctx *c) { // push messages only (walk results go by direct atomics in the wide layout)
+    if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
     return 196608; // also holds the indexed walk results (~omega*rsum/nbins per bucket)
 }
 
@@ -231,8 +260,8 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
-        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins()) : p.nbins;
-        p.bk_cap = (uint32_t)std::min<uint64_t>((uint64_t)(want_wide(c) ? want_bk_cap_wide() : want_bk_cap()) * c->bk_scale, 1u << 28);
+        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c)) : p.nbins;
+        p.bk_cap = (uint32_t)std::min<uint64_t>((uint64_t)(want_wide(c) ? want_bk_cap_wide(c) : want_bk_cap(c)) * c->bk_scale, 1u << 28);
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
@@ -248,7 +277,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
 int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
     const int npass = pbins > 0 ? (nbins + pbins - 1) / pbins : 1;
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
-    if (npass <= 1 || getenv("FORA_HIP_NO_SPLIT")) { dfree(c->d_col_push); dfree(c->d_row_split); c->split_pbins = 0; return FORA_OK; }
+    if (npass <= 1 || c->opt_.no_split) { dfree(c->d_col_push); dfree(c->d_row_split); c->split_pbins = 0; return FORA_OK; }
     if (c->d_row_split && c->split_pbins == pbins) return FORA_OK;
     dfree(c->d_col_push); dfree(c->d_row_split);
     const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
@@ -306,7 +335,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_inc_tab[0], (uint64_t)B * p.segq_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_inc_tab[1], (uint64_t)B * p.segq_cap * 8));
         c->ov_cap = (uint32_t)std::max<uint64_t>(262144, n / 8); // bucket-overflow list, scales with the graph
-        if (const char *e = getenv("FORA_HIP_OVCAP")) if (atoi(e) > 0) c->ov_cap = (uint32_t)atoi(e); // tests
+        if (c->opt_.ovcap > 0) c->ov_cap = (uint32_t)c->opt_.ovcap; // tests
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
@@ -366,8 +395,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.row_split = c->d_row_split;
     d.npass = c->pbins > 0 ? (c->nbins + c->pbins - 1) / c->pbins : 1;
     d.pass = 0;
-    d.tiny_max = 512; // ws: accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193
-    if (const char *e = getenv("FORA_HIP_TINY")) if (atoi(e) >= 0) d.tiny_max = (uint32_t)atoi(e);
+    d.tiny_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.tiny, 0), 1023); // 512: ws accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193 (the crossing list of the small-bucket path holds 1024)
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
     d.inc_tab[0] = c->d_inc_tab[0]; d.inc_tab[1] = c->d_inc_tab[1]; d.segq_cap = c->segq_cap;
@@ -438,11 +466,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     int L = 0;
     const int nq = d.nq;
     unsigned xb = (unsigned)std::min(1024, std::max(16, 16384 / std::max(1, nq))); // blocks per slot; ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
-    if (const char *e = getenv("FORA_HIP_XB")) if (atoi(e) > 0) xb = (unsigned)atoi(e);
-    uint32_t tail_max = 1024; // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
-    if (const char *e = getenv("FORA_HIP_TAIL")) tail_max = (uint32_t)std::max(0, atoi(e));
-    const char *ta = getenv("FORA_HIP_TAIL_ALWAYS"); // tests: do not wait for the frontier to have been large first
-    bool past_peak = ta && ta[0] == '1';
+    if (c->opt_.xb > 0) xb = (unsigned)c->opt_.xb;
+    // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
+    const uint32_t tail_max = (uint32_t)std::max<int64_t>(0, c->opt_.tail);
+    bool past_peak = c->opt_.tail_always == 1; // tests: do not wait for the frontier to have been large first
     for (;; L++) {
         if (level_cap > 0 && L >= level_cap) break; // power iteration: a fixed number of levels
         if (L >= MAX_LEVELS) { rc = fail(c, FORA_E_OVERFLOW, "push level cap reached"); break; }
@@ -519,9 +546,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
 // ties keep resolving to the lowest ids) into the push's frontier / increment buffers, which are idle here.
 constexpr unsigned NZ_X = 1024;
 int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, double *scores, int raw) {
-    const char *e = getenv("FORA_HIP_SELECT_COMPACT"); // tests: force (1) or forbid (0) the compacted form
     bool compact = c->binned && c->n >= (1 << 20);
-    if (e) compact = c->binned && e[0] == '1';
+    if (c->opt_.select_compact >= 0) compact = c->binned && c->opt_.select_compact == 1; // tests: force / forbid the compacted form
     if (!compact) {
         hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, ids, scores, raw,
                            (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr);
@@ -566,7 +592,7 @@ enum { RUN_PUSH_ONLY = 1 };
 
 // refinement launches after k_walk_alloc: indexed walks, online walks, and the accumulate of their results
 void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t round, int nzh) {
-    const dim3 wg(walk_grid_x(nq), nq);
+    const dim3 wg(walk_grid_x(c, nq), nq);
     int h = ev_begin(c, 3);
     if (with_idx) {
         if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, wg, dim3(BLOCK), 0, c->stream, d);
@@ -727,6 +753,7 @@ int sync_twin(fora_ctx *c) {
         w->prop = c->prop;
         if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return fail(c, FORA_E_HIP, "twin stream"); }
         w->profiling = c->profiling;
+        w->opt_ = c->opt_;
         w->grid_blocks = c->grid_blocks;
         c->twin = w;
     }
@@ -742,6 +769,7 @@ int sync_twin(fora_ctx *c) {
     w->idx_len = c->idx_len; w->have_index = c->have_index;
     w->bk_scale = c->bk_scale;
     w->d_stamps = c->d_stamps;
+    w->opt_ = c->opt_;
     w->balanced = c->balanced; w->bal_start = c->bal_start; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
     w->batch_req = c->B; // same slot count as the first lane
     return FORA_OK;
@@ -760,8 +788,7 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
     const uint64_t n = (uint64_t)c->n;
     // second lane when there is more than one batch to run
     fora_ctx *lanes[2] = {c, c};
-    const char *pe = getenv("FORA_HIP_PIPELINE");
-    if (nq > c->B && pe && pe[0] == '1') { // opt-in: measured no gain on ws (kernels time-slice)
+    if (nq > c->B && c->opt_.pipeline == 1) { // opt-in: measured no gain on ws (kernels time-slice)
         rc = sync_twin(c);
         if (rc) return rc;
         rc = ensure_workspace(c->twin, c->B, c->omega);
@@ -817,15 +844,44 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
 // A batch whose message buckets (and their overflow list) were too small is not a caller error: double the bucket
 // capacity, re-plan the workspace and run the call again from scratch (results never depend on the capacity).
 template <class F> int with_bucket_retry(fora_ctx *c, F call) {
+    const uint32_t scale0 = c ? c->bk_scale : 1;
     for (;;) {
+        const fora_timing t0 = c ? c->timing : fora_timing{};
         const int rc = call();
-        if (!c || rc != FORA_E_OVERFLOW) return rc;
+        if (!c || rc != FORA_E_OVERFLOW) {
+            if (c && rc != FORA_OK && c->bk_scale != scale0) { // the enlarged plan did not help: do not keep it
+                c->bk_scale = scale0;
+                (void)hipSetDevice(c->device);
+                free_workspace(c);
+                if (c->twin) { c->twin->bk_scale = scale0; free_workspace(c->twin); }
+            }
+            return rc;
+        }
         const bool bucket = c->bucket_overflow || (c->twin && c->twin->bucket_overflow);
-        if (!bucket || c->bk_scale >= (1u << 16)) return rc;
+        if (!bucket || c->bk_scale >= (1u << 16)) {
+            if (c->bk_scale != scale0) {
+                c->bk_scale = scale0;
+                (void)hipSetDevice(c->device);
+                free_workspace(c);
+                if (c->twin) { c->twin->bk_scale = scale0; free_workspace(c->twin); }
+            }
+            return rc;
+        }
         c->bk_scale *= 2;
         c->bucket_overflow = false;
-        if (c->twin) { c->twin->bucket_overflow = false; }
+        // the failed attempt must leave no trace in the timings: drop its event pairs and counters
         (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        c->ev_used = 0;
+        c->timing = t0;
+        c->pending_nq = 0;
+        if (c->twin) {
+            c->twin->bucket_overflow = false;
+            (void)hipStreamSynchronize(c->twin->stream);
+            c->twin->ev_used = 0;
+            c->twin->pending_nq = 0;
+            c->twin->bk_scale = c->bk_scale;
+        }
         free_workspace(c);
         if (c->twin) free_workspace(c->twin);
     }
@@ -866,10 +922,9 @@ int fora_hip_create(int device, fora_ctx **out) {
         delete c;
         return FORA_E_NOMEM;
     }
-    const char *p = getenv("FORA_HIP_PROFILE");
-    if (p && p[0] == '0') c->profiling = false;
-    const char *g = getenv("FORA_HIP_GRID");
-    if (g && atoi(g) > 0) c->grid_blocks = atoi(g);
+    c->opt_ = tunables_from_env();
+    c->profiling = c->opt_.profile != 0;
+    if (c->opt_.grid > 0) c->grid_blocks = (int)c->opt_.grid;
     *out = c;
     return FORA_OK;
 }
@@ -937,8 +992,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     if (nnz) HIPCHK(c, hipMemcpy(c->d_col, col, (size_t)nnz * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_rowinfo, rowinfo.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_deg, deg.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    const char *nc = getenv("FORA_HIP_NO_COMPACT");
-    if (nnz < (1ll << 31) && !(nc && nc[0] == '1')) { // compact walk-step copy
+    if (nnz < (1ll << 31) && c->opt_.no_compact != 1) { // compact walk-step copy
         uint32_t bits = 1;
         while ((1ull << bits) < (uint64_t)n) bits++;
         if (bits > 31) bits = 31;
@@ -1002,6 +1056,27 @@ int fora_hip_set_batch(fora_ctx *c, int batch) {
 }
 int fora_hip_get_batch(fora_ctx *c) { return c ? c->B : FORA_E_ARG; }
 
+int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return FORA_E_ARG;
+    if (!strcmp(name, "reset")) { // back to the defaults / environment of fora_hip_create
+        (void)hipSetDevice(c->device);
+        free_workspace(c);
+        if (c->twin) free_workspace(c->twin);
+        c->opt_ = tunables_from_env();
+        c->profiling = c->opt_.profile != 0;
+        return FORA_OK;
+    }
+    for (const auto &o : OPTIONS)
+        if (!strcmp(name, o.name)) {
+            if (c->opt_.*(o.field) == value) return FORA_OK;
+            c->opt_.*(o.field) = value;
+            if (o.layout) { (void)hipSetDevice(c->device); free_workspace(c); if (c->twin) free_workspace(c->twin); }
+            if (!strcmp(name, "profile")) c->profiling = value != 0;
+            return FORA_OK;
+        }
+    return fail(c, FORA_E_ARG, std::string("unknown option ") + name);
+}
+
 int fora_hip_set_balanced(fora_ctx *c, int on, double start_scale, double c_pop, double c_edge, double t_walk, double t_idx) {
     if (!c) return FORA_E_ARG;
     c->balanced = on != 0;
@@ -1059,7 +1134,7 @@ int fora_hip_build_index(fora_ctx *c) {
     hipLaunchKernelGGL(k_index_alloc, dim3(chunks), dim3(BLOCK), 0, c->stream, d);
     ev_end(c, h);
     h = ev_begin(c, 3);
-    hipLaunchKernelGGL(k_walk_online<WALK_TO_INDEX>, dim3(walk_grid_x(1), 1), dim3(BLOCK), 0, c->stream, d, 0u,
+    hipLaunchKernelGGL(k_walk_online<WALK_TO_INDEX>, dim3(walk_grid_x(c, 1), 1), dim3(BLOCK), 0, c->stream, d, 0u,
                        c->opt ? 1 : 0, c->d_rw_idx);
     ev_end(c, h);
     rc = check_dev_err(c);

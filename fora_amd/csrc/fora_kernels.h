@@ -1552,7 +1552,7 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
         if ((t & 1u) == 0)
             philox4x32_10(start, (uint32_t)j,
                           (uint32_t)((j >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
-                          stream, d.seed_lo, d.seed_hi, w);
+                          stream ^ ((t >> 9) * 0x9E3779B9u), d.seed_lo, d.seed_hi, w); // (t >> 9): steps 512.. get fresh streams
         const uint32_t ws = (t & 1u) ? w[2] : w[0], wm = (t & 1u) ? w[3] : w[1];
         if (!(nzh && t == 0) && ws < d.alpha32) return (int32_t)cur; // algo.h:131-133
         if (t) node_row(d, cur, beg, deg);
@@ -1884,7 +1884,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
                 if (active)
                     philox4x32_10(start, (uint32_t)wj,
                                   (uint32_t)((wj >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
-                                  stream, d.seed_lo, d.seed_hi, rw);
+                                  stream ^ ((t >> 9) * 0x9E3779B9u), d.seed_lo, d.seed_hi, rw);
             }
             if (active) {
                 const uint32_t ws = (it & 1u) ? rw[2] : rw[0], wm = (it & 1u) ? rw[3] : rw[1];

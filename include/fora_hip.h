@@ -112,6 +112,11 @@ int fora_hip_set_balanced(fora_ctx *ctx, int on, double start_scale, double c_po
 /* queries processed concurrently per launch; 0 = choose from free HBM */
 int fora_hip_set_batch(fora_ctx *ctx, int batch);
 int fora_hip_get_batch(fora_ctx *ctx);
+/* Engine knobs (layout choice, launch shapes, capacities; the list is `OPTIONS` in fora_hip.hip).  Every knob is read
+ * once, in fora_hip_create, from the environment variable FORA_HIP_<NAME>; this call changes one afterwards (tests
+ * use it to force the wide layout, tiny buckets, the k_push_tail path ...).  No knob changes a result bit.
+ * name "reset": back to the values fora_hip_create read.  Unknown name: FORA_E_ARG. */
+int fora_hip_set_option(fora_ctx *ctx, const char *name, int64_t value);
 
 /* ---- walk index: replaces build() (build.h:302-366), rw_idx / rw_idx_info
  * (algo.h:42-43) and deserialize_idx() (build.h:194-207) ------------------- */

@@ -141,7 +141,9 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  * Bernoulli(alpha) stop test comes BEFORE each move; a dangling current node
  * jumps back to the start and the walk goes on.
  * Randomness: one Philox call per two steps, counter =
- *   (start, j lo32, j bits 32..47 | round<<16 | (step/2 & 255)<<24, stream),
+ *   (start, j lo32, j bits 32..47 | round<<16 | (step/2 & 255)<<24, stream ^ (step>>9)*0x9E3779B9),
+ * (the last word moves on every 512 steps: the 8-bit step field alone would repeat its draws with period 512,
+ *  and a walk that survived one period would never stop -- certain at small alpha and 1e8+ walks),
  * key = (seed lo32, seed hi32).  Step t uses words 2(t&1) [stop if < floor(alpha*2^32)]
  * and 2(t&1)+1 [neighbour = (word*deg)>>32]. */
 int32_t orc_walk(int32_t n, const int64_t *row_ptr, const int32_t *col, uint64_t seed,
@@ -159,7 +161,7 @@ int32_t orc_walk(int32_t n, const int64_t *row_ptr, const int32_t *col, uint64_t
             uint32_t ctr[4] = {(uint32_t)start, (uint32_t)j,
                                (uint32_t)((j >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) |
                                    (((t >> 1) & 0xFFu) << 24),
-                               stream};
+                               stream ^ ((t >> 9) * 0x9E3779B9u)};
             orc_philox4x32_10(ctr, key, w);
         }
         uint32_t ws = w[(t & 1u) * 2], wm = w[(t & 1u) * 2 + 1];

@@ -146,6 +146,13 @@ def walk(g, seed, stream, rnd, start, j, alpha=0.2, no_zero_hop=False):
                           C.c_int(int(no_zero_hop)), None)
 
 
+def walk_steps(g, seed, stream, rnd, start, j, alpha=0.2, no_zero_hop=False):
+    steps = C.c_int64(0)
+    lib().orc_walk(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), C.c_uint64(seed), C.c_uint32(stream),
+                   C.c_uint32(rnd), C.c_int32(start), C.c_uint64(j), _d(alpha), C.c_int(int(no_zero_hop)), C.byref(steps))
+    return steps.value
+
+
 def push_fifo(g, s, rmax, alpha=0.2):
     reserve = np.zeros(g.n, dtype=np.float64)
     residue = np.zeros(g.n, dtype=np.float64)

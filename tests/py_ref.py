@@ -101,7 +101,7 @@ def walk(adj, seed, stream, rnd, start, j, alpha=0.2, no_zero_hop=False):
     w = None
     while True:
         if t % 2 == 0:
-            w = philox4x32_10((start & M32, j & M32, ((j >> 32) & 0xFFFF) | ((rnd & 0xFF) << 16) | (((t >> 1) & 0xFF) << 24), stream), key)
+            w = philox4x32_10((start & M32, j & M32, ((j >> 32) & 0xFFFF) | ((rnd & 0xFF) << 16) | (((t >> 1) & 0xFF) << 24), (stream ^ ((t >> 9) * 0x9E3779B9)) & M32), key)
         ws, wm = w[(t & 1) * 2], w[(t & 1) * 2 + 1]
         if not (no_zero_hop and t == 0) and ws < alpha32:
             return cur

@@ -92,9 +92,9 @@ def test_bucket_overflow_is_retried_with_larger_buckets(engine, oracle, small, m
     """Buckets and overflow list far too small for the graph: the call doubles the bucket capacity and runs again until
     the level fits (8 -> 65 536 messages here) instead of failing; results are the twin's bits as always."""
     g = small
-    monkeypatch.setenv("FORA_HIP_BKCAP", "8")
-    monkeypatch.setenv("FORA_HIP_OVCAP", "64")
-    monkeypatch.setenv("FORA_HIP_TAIL", "0")
+    engine.set_option("bkcap", 8)
+    engine.set_option("ovcap", 64)
+    engine.set_option("tail", 0)
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = pick_sources(g, 4, 301)
     ppr, res, st = engine.query_fix(srcs)
@@ -104,6 +104,5 @@ def test_bucket_overflow_is_retried_with_larger_buckets(engine, oracle, small, m
     ids, sc, rounds = engine.topk_bound(srcs[:2], 50, epsilon=0.5)   # the enlarged plan is kept for later calls
     wid, wsc, wr, _, _, _ = oracle.twin_topk_bound_query(g, int(srcs[0]), 50, 0.5, seed=SEED)
     assert rounds[0] == wr and (ids[0] == wid).all() and (sc[0] == wsc).all()
-    for k in ("FORA_HIP_BKCAP", "FORA_HIP_OVCAP", "FORA_HIP_TAIL"):
-        monkeypatch.delenv(k)
+    engine.reset_options()
     engine.set_graph(g.n, g.m, g.row_ptr, g.col)   # a new graph starts from the default capacity again

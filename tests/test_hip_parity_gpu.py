@@ -71,6 +71,28 @@ def test_walk_endpoints_bit_exact(engine, oracle, small_dangling):
             assert (got == want).all()
 
 
+def test_long_walks_bit_exact(engine, oracle, tiny):
+    """alpha = 0.004: 13 % of the walks outlive the 512-step period of the counter's step field and must still end
+    (the last counter word moves on every 512 steps) at the oracle's endpoints."""
+    g = tiny
+    engine.clear_index()
+    engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+    engine.set_params(alpha=0.004, epsilon=0.5, seed=SEED)
+    rng = np.random.Generator(np.random.PCG64(31))
+    starts = rng.choice(np.flatnonzero(g.deg > 0), size=600).astype(np.int32)
+    js = rng.integers(0, 1 << 44, size=600).astype(np.uint64)
+    got = engine.walks(9, 0, starts, js)
+    want = np.array([oracle.walk(g, SEED, 9, 0, int(v), int(j), alpha=0.004) for v, j in zip(starts, js)], dtype=np.int32)
+    assert (got == want).all()
+    assert sum(oracle.walk_steps(g, SEED, 9, 0, int(v), int(j), alpha=0.004) > 512 for v, j in zip(starts[:100], js[:100])) >= 3
+    # and through the product path: an online-walk query at this alpha conserves mass exactly and matches the twin
+    rmax, omega = engine.get_params()
+    ppr, _, st = engine.query_fix(starts[:2])
+    for i in range(2):
+        want, _, _ = oracle.twin_query(g, int(starts[i]), rmax, omega, alpha=0.004, seed=SEED)
+        assert (ppr[i] == want).all() and st[i]["ppr_sum_fix"] == oracle.FIX_ONE
+
+
 @pytest.mark.parametrize("opt", [False, True])
 @pytest.mark.parametrize("gname", ["tiny_dangling", "small"])
 def test_query_bit_exact_vs_twin(engine, oracle, request, gname, opt):
@@ -260,27 +282,27 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         assert (np.diff(g.col[g.row_ptr[np.argmax(g.deg)]:g.row_ptr[np.argmax(g.deg) + 1]]) < 0).any()
         mode = "bucketed_wide_multipass"
     if mode == "bucketed_wide_multipass_nosplit":  # every pass scans whole rows and filters by bin range
-        monkeypatch.setenv("FORA_HIP_NO_SPLIT", "1")
+        engine.set_option("no_split", 1)
         mode = "bucketed_wide_multipass"
     # the bucketed levels are what these modes are about: keep k_push_tail (which takes over once every frontier is
     # small -- on a 32 k-node graph almost at once) out of them, except where it is the subject
-    monkeypatch.setenv("FORA_HIP_TAIL", "100000000" if mode.startswith("tail") else "0")
+    engine.set_option("tail", 100000000 if mode.startswith("tail") else 0)
     if mode.startswith("tail"):
-        monkeypatch.setenv("FORA_HIP_TAIL_ALWAYS", "1")
+        engine.set_option("tail_always", 1)
     if mode == "tail_wide_multipass":
         mode = "bucketed_wide_multipass"
     if mode == "direct":
-        monkeypatch.setenv("FORA_HIP_DIRECT", "1")
+        engine.set_option("direct", 1)
     elif mode == "bucketed_overflow":
-        monkeypatch.setenv("FORA_HIP_BKCAP", "96")
+        engine.set_option("bkcap", 96)
     elif mode == "bucketed_wide":
-        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
+        engine.set_option("force_wide", 1)
     elif mode == "bucketed_wide_overflow":
-        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
-        monkeypatch.setenv("FORA_HIP_BKCAP", "200")
+        engine.set_option("force_wide", 1)
+        engine.set_option("bkcap", 200)
     elif mode == "bucketed_wide_multipass":  # the layout of graphs with more than 1024 bins: several passes per level
-        monkeypatch.setenv("FORA_HIP_FORCE_WIDE", "1")
-        monkeypatch.setenv("FORA_HIP_PASS_BINS", "1")
+        engine.set_option("force_wide", 1)
+        engine.set_option("pass_bins", 1)
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = np.concatenate([pick_sources(g, 7, 51), pick_sources(g, 1, 52, want_dangling=True)])
     ppr, res, st = engine.query_fix(srcs)
@@ -288,8 +310,8 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         want, wres, wst = oracle.twin_query(g, int(s), rmax, omega, seed=SEED)
         assert (res[i] == wres).all() and (ppr[i] == want).all()
         assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["levels"] == wst["levels"]
-    monkeypatch.delenv("FORA_HIP_DIRECT", raising=False)
-    monkeypatch.delenv("FORA_HIP_BKCAP", raising=False)
+    engine.set_option("direct", 0)
+    engine.set_option("bkcap", 0)
     if mode == "bucketed_wide_multipass":  # indexed walks and top-k take the per-pass route too
         engine.build_index()
         idx = engine.get_index()
@@ -298,11 +320,7 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
             want, _, _ = oracle.twin_query(g, int(s), rmax, omega, seed=SEED, index=idx)
             assert (pi[i] == want).all()
         engine.clear_index()
-    monkeypatch.delenv("FORA_HIP_FORCE_WIDE", raising=False)
-    monkeypatch.delenv("FORA_HIP_PASS_BINS", raising=False)
-    monkeypatch.delenv("FORA_HIP_NO_SPLIT", raising=False)
-    monkeypatch.delenv("FORA_HIP_TAIL", raising=False)
-    monkeypatch.delenv("FORA_HIP_TAIL_ALWAYS", raising=False)
+    engine.reset_options()
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
@@ -313,9 +331,9 @@ def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
     srcs = pick_sources(g, 10, 61)
     engine.set_batch(3)
     a, ra, _ = engine.query_fix(srcs)
-    monkeypatch.setenv("FORA_HIP_PIPELINE", "1")
+    engine.set_option("pipeline", 1)
     b, rb, st = engine.query_fix(srcs)
-    monkeypatch.delenv("FORA_HIP_PIPELINE")
+    engine.set_option("pipeline", 0)
     engine.set_batch(0)
     assert (a == b).all() and (ra == rb).all()
     assert all(s["ppr_sum_fix"] == oracle.FIX_ONE for s in st)
@@ -446,10 +464,10 @@ def test_topk_select_compacted_form_same_lists(engine, oracle, small_dangling, m
     srcs = np.concatenate([pick_sources(g, 5, 99), pick_sources(g, 1, 100, want_dangling=True)])
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FORA_HIP_SELECT_COMPACT", mode)
+        engine.set_option("select_compact", int(mode))
         out[mode] = (engine.topk(srcs, 300, epsilon=0.5), engine.topk_bound(srcs, 300, epsilon=0.5),
                      engine.power_iteration(srcs, max_iter=3, k=700, want_ppr=False)[2:])
-    monkeypatch.delenv("FORA_HIP_SELECT_COMPACT")
+    engine.reset_options()
     for a, b in zip(out["0"], out["1"]):
         for x, y in zip(a, b):
             assert (np.asarray(x) == np.asarray(y)).all()

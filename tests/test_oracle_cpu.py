@@ -102,6 +102,24 @@ def test_walk_matches_python_restatement(oracle, tiny_dangling):
             py_ref.walk(adj, 0x464F5241, 77, rnd, v, j, no_zero_hop=nzh)
 
 
+def test_long_walks_leave_the_512_step_period(oracle, tiny):
+    """The step field of the Philox counter has 8 bits (one call per two steps): without the (step >> 9) term in the
+    last counter word a walk that survives 512 steps would replay its draws for ever.  alpha = 0.004 makes such walks
+    common (0.996^512 = 13 %); both restatements agree on them and none runs away."""
+    g = tiny
+    adj = _adj(g)
+    rng = np.random.Generator(np.random.PCG64(6))
+    long_ones = 0
+    for _ in range(60):
+        v = int(rng.choice(np.flatnonzero(g.deg > 0)))
+        j = int(rng.integers(0, 1 << 40))
+        steps = oracle.walk_steps(g, 0x464F5241, 3, 0, v, j, alpha=0.004)
+        long_ones += steps > 512
+        assert steps < 20000
+        assert oracle.walk(g, 0x464F5241, 3, 0, v, j, alpha=0.004) == py_ref.walk(adj, 0x464F5241, 3, 0, v, j, alpha=0.004)
+    assert long_ones >= 2
+
+
 # ---- invariants of both families (SURVEY.md section 4, last row)
 @pytest.mark.parametrize("gname", ["small", "small_dangling"])
 def test_push_invariants(oracle, request, gname):
