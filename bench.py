@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- SSPPR queries/sec of the HIP FORA path (BASELINE.json metric).
 
-One "step" = one pass of the hot path (forward push + random-walk refinement) over a
-batch of --queries synthetic source queries on this rank's GPU.  Default workload is
-BASELINE.json configs[1]: webstanford-sized graph, eps=0.5, query_size=1000, online
-walks (no index), 1 x MI355X.  N>1: one process per GPU (torch.distributed.run), the
-global query list is sharded i mod N, no data-path collective (weak scaling: every
-rank runs --queries queries per step).
+One "step" = one pass of the hot path (forward push + random-walk refinement, or the top-k driver with --topk)
+over a batch of synthetic source queries.  Workloads (BASELINE.json configs):
+
+  default                                   config 2: webstanford-sized, eps=0.5, query_size=1000, online walks, 1 GPU
+  --graph livejournal --with-idx            config 3: LiveJournal-sized, indexed walks in HBM
+  --graph twitter2010 --with-idx --gpus 8 --scaling strong --queries 1000
+                                            config 4: Twitter-2010-sized, 1000 sources sharded i mod 8
+  --graph twitter2010 --topk 500 --with-idx --gpus 8 --scaling strong --queries 1000
+                                            config 5: top-k (k=500, --opt), RCCL all-gather of the lists inside the timed region
+
+--gpus N: one process per GPU.  Started by `python -m torch.distributed.run` (the driver's way) this file is a rank;
+started plainly with --gpus N > 1 it launches that same command itself, before anything touches a GPU.
+--scaling weak (default): every rank runs --queries sources per step; strong: --queries sources in total, source i on
+rank i mod N (query.h:1471-1476 has no cross-query state).  No data-path collective for `query`; `topk` ends every
+step with one all-gather of fixed-size [ceil(Q/N), k] (int32 id, f64 score) lists.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,16 +33,19 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+DEFAULT_QUERIES = {"twitter2010": 125}  # one GPU's share of config 4 (1000 sources over 8 GPUs); everything else 1000
+DTYPE = "u64 fixed-point 2^-62 (f64 at the boundary)"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--graph", default="webstanford", help="synth preset (webstanford|livejournal|small|tiny)")
+    ap.add_argument("--graph", default="webstanford", help="synth preset (webstanford|medium|livejournal|twitter2010|small|tiny)")
     ap.add_argument("--dangling", default="none", choices=["none", "rmat"])
-    ap.add_argument("--queries", type=int, default=1000, help="query_size per rank per step")
+    ap.add_argument("--queries", type=int, default=0, help="query_size (per rank with --scaling weak, in total with strong); 0: per graph")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--epsilon", type=float, default=0.5)
     ap.add_argument("--with-idx", action="store_true")
     ap.add_argument("--opt", action="store_true")
@@ -43,11 +57,41 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --balanced timing")
-    ap.add_argument("--no-accuracy", action="store_true", help="skip the L-inf check against GPU power iteration")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the L-inf check against exact PPR")
     ap.add_argument("--topk", type=int, default=0, help="k > 0: time `topk --opt` (config 5 style) instead of `query`")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
-                    help="per-kernel FETCH_SIZE/WRITE_SIZE summary from separate rocprofv3 --pmc passes (tools/pmc_summary.py)")
-    return ap.parse_args()
+    ap.add_argument("--traffic", default="", help="per-kernel FETCH_SIZE/WRITE_SIZE summary from separate rocprofv3 --pmc passes "
+                                                  "(tools/pmc_summary.py); default profiles/pmc_traffic_<graph>[_idx].json")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="test hook (tests/test_dist_cpu.py): launcher, sharding, barrier / max-over-ranks timing and the top-k "
+                         "gather with gloo on CPU and a stand-in step; no GPU, no engine")
+    args = ap.parse_args(argv)
+    if not args.queries:
+        args.queries = DEFAULT_QUERIES.get(args.graph, 1000)
+    return args
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start N ranks of this file (fresh children; this process has not
+    touched a GPU and never will) and pass their exit code on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def my_sources(np, synth, n, args, rank, world):
+    """Global query list and this rank's shard.  weak: --queries per rank; strong: --queries in total.  Source i of the
+    global list runs on rank i mod world either way."""
+    from fora_amd.dist import shard_sources
+    total = args.queries * world if args.scaling == "weak" else args.queries
+    all_sources = synth.query_set(n, total, 20261001)
+    return all_sources, shard_sources(all_sources, rank, world)
 
 
 def cpu_baseline(g, sources, rmax, omega, args, index):
@@ -67,10 +111,10 @@ def cpu_baseline(g, sources, rmax, omega, args, index):
     t1 = time.perf_counter()
     ppops, prelax, pn = pops, relax, done
     for s in sources[done:done + 96]:
-        p = O.push_fifo(g, int(s), rmax)
-        ppops += p["pops"]; prelax += p["relax"]; pn += 1
         if time.perf_counter() - t1 > 0.5 * args.cpu_seconds:
             break
+        p = O.push_fifo(g, int(s), rmax)
+        ppops += p["pops"]; prelax += p["relax"]; pn += 1
     return {
         "value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": f"first {done} of the {len(sources)} bench sources, oracle FIFO push + "
@@ -102,40 +146,110 @@ def cpu_all_cores(g, sources, rmax, omega, args, index, threads):
             "sample": f"{done} of the bench sources over {threads} threads (sources tid mod T), {dt:.1f} s"}
 
 
-def accuracy(eng, sources, n, args, np):
-    """BASELINE metric, second half: L-inf PPR error.  Exact vector = fwd_power_iteration (query.h:1192-1224,
-    100 iterations) run on the GPU (fora_hip_power_iteration_batch, bit-checked against the twin in tests)."""
+def accuracy(eng, g, sources, n, m, args, np):
+    """BASELINE metric, second half: L-inf PPR error against exact PPR = fwd_power_iteration (query.h:1192-1224, 100
+    iterations).  The first sources are checked against the CPU restatement of that function in f64
+    (oracle/fora_oracle.c orc_power_iteration -- independent of the HIP library), the rest against the same iteration
+    run on the GPU (fora_hip_power_iteration_batch, bit-checked against the twin in tests)."""
     ns = min(len(sources), 8 if n <= 10_000_000 else 2)
+    n_cpu = 0 if g is None else (2 if m <= 20_000_000 else 1 if m <= 200_000_000 else 0)  # 100 sweeps of m edges on one core
+    n_cpu = min(n_cpu, ns)
     est, _ = eng.query(sources[:ns], with_idx=args.with_idx)
     exact, _, _, _ = eng.power_iteration(sources[:ns], max_iter=100)
+    cpu_vs_gpu_exact = None
+    if n_cpu:
+        import oracle_lib as O
+        cpu_exact = np.stack([O.power_iteration(g, int(s)) for s in sources[:n_cpu]])
+        cpu_vs_gpu_exact = float(np.abs(cpu_exact - exact[:n_cpu]).max())
+        exact[:n_cpu] = cpu_exact
     err = np.abs(est - exact)
     big = exact >= 1.0 / n
     rel = float((err[big] / exact[big]).max()) if big.any() else 0.0
     return {"sources": int(ns), "linf_abs_err": float(err.max()), "max_rel_err_where_pi_ge_1_over_n": rel,
             "guarantee": f"rel err <= eps = {args.epsilon} for pi >= 1/n (algo.h:455-463)", "holds": bool(rel <= args.epsilon),
-            "exact": "GPU power iteration, 100 iterations (query.h:1192-1224)"}
+            "exact": f"power iteration, 100 iterations (query.h:1192-1224): first {n_cpu} sources on the CPU in f64 "
+                     f"(oracle), the others on the GPU",
+            "cpu_vs_gpu_exact_linf": cpu_vs_gpu_exact}
+
+
+def plumbing_only(args):
+    """Same launcher / sharding / timing / gather code path as the real run, with gloo on CPU and a stand-in step."""
+    import numpy as np
+    import torch.distributed as dist
+    from fora_amd import synth
+    from fora_amd.dist import env_world, max_over_ranks, sum_over_ranks, gather_topk
+    rank, _, world = env_world()
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+    n = 1000
+    all_sources, mine = my_sources(np, synth, n, args, rank, world)
+    k = max(1, args.topk)
+    g_ids = None
+
+    def step():
+        nonlocal g_ids
+        time.sleep(0.01 * (rank + 1))
+        ids = np.repeat(mine[:, None], k, axis=1).astype(np.int32)  # stand-in lists: query i -> k copies of its source id
+        sc = np.tile(np.arange(k, 0, -1, dtype=np.float64), (len(mine), 1))
+        g_ids, _ = gather_topk(ids, sc, len(all_sources), rank, world if use_dist else 1)
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if use_dist:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world if use_dist else 1)
+    tot = sum_over_ranks([len(mine)], world if use_dist else 1)
+    ok = bool((g_ids[:, 0] == all_sources).all())
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing-only", "value": tot[0] * args.steps / dt, "unit": "queries/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                          "higher_is_better": True, "scaling": args.scaling, "queries_total_per_step": int(tot[0]),
+                          "gather_in_global_order": ok}))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
     args = parse()
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # started by torch.distributed.run
+    if args.gpus > 1 and not under_launcher:
+        return launch(args)
+    if under_launcher and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}", file=sys.stderr)
+        return 2
+    if args.plumbing_only:
+        return plumbing_only(args)
     import torch  # first: the process must use ONE HIP runtime (torch's), the library binds to it
     import torch.distributed as dist
     import numpy as np
     import fora_amd
     from fora_amd import synth
-    from fora_amd.dist import env_world, shard_sources, max_over_ranks, sum_over_ranks
+    from fora_amd.dist import env_world, max_over_ranks, sum_over_ranks, gather_topk
 
     rank, local_rank, world = env_world()
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    use_dist = under_launcher
     torch.cuda.set_device(local_rank)
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank)
 
+    t0 = time.perf_counter()
     n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
+    t_graph = time.perf_counter() - t0
     eng = fora_amd.Engine(local_rank)
     arch, cus, hbm = eng.device_info()
+    t0 = time.perf_counter()
     eng.set_graph(n, m, row_ptr, col)
+    t_upload = time.perf_counter() - t0
     eng.set_params(alpha=0.2, epsilon=args.epsilon, opt=args.opt or bool(args.topk), seed=0x464F5241)
     rmax, omega = eng.get_params()
     if args.batch:
@@ -148,16 +262,16 @@ def main():
         eng.build_index()
         t_idx = time.perf_counter() - t0
 
-    # global query list, sharded i mod world; every rank gets --queries sources per step
-    all_sources = synth.query_set(n, args.queries * world, 20261001)
-    mine = shard_sources(all_sources, rank, world)
-
+    all_sources, mine = my_sources(np, synth, n, args, rank, world)
+    q_step_total = len(all_sources)
     topk_out = {}
 
     def step():
         if args.topk:
             ids, sc, rounds = eng.topk(mine, args.topk, epsilon=args.epsilon, with_idx=args.with_idx)
-            topk_out["ids"], topk_out["sc"], topk_out["rounds"] = ids, sc, rounds
+            # the one collective of the design: fixed-size lists to every rank, in global query order
+            g_ids, g_sc = gather_topk(ids, sc, q_step_total, rank, world if use_dist else 1, dev if use_dist else None)
+            topk_out["ids"], topk_out["sc"], topk_out["rounds"] = g_ids, g_sc, rounds
             return None
         _, st = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
         return st
@@ -179,29 +293,33 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world if use_dist else 1, dev)
     tm = eng.timing()
+    shard = f"sources i mod {world}"
+    qdesc = (f"query_size={args.queries}/GPU" if args.scaling == "weak" else f"query_size={args.queries} in total ({shard})")
 
     if args.topk:
-        # top-k: gather the per-rank lists (RCCL all-gather when distributed), check they are sorted
-        from fora_amd.dist import gather_topk
-        g_ids, g_sc = gather_topk(topk_out["ids"], topk_out["sc"], len(mine) * world, rank, world if use_dist else 1,
-                                  dev if use_dist else None)
+        g_sc = topk_out["sc"]
+        assert g_sc.shape == (q_step_total, args.topk)
         assert (np.diff(g_sc, axis=1) <= 0).all()
+        rounds_all = sum_over_ranks([float(np.sum(topk_out["rounds"])), float(len(mine))], world if use_dist else 1, dev)
         if rank == 0:
-            dtq = dt
             print(json.dumps({
-                "metric": "SSPPR top-k queries/sec at eps=0.5", "value": len(mine) * world * args.steps / dtq,
+                "metric": "SSPPR top-k queries/sec at eps=0.5", "value": q_step_total * args.steps / dt,
                 "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * dtq / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "u64 fixed-point 2^-62 (f64 at the boundary)", "data": "synthetic",
-                "config": {"workload": f"{args.graph}-sized R-MAT topk k={args.topk} --opt"
-                                       f"{' --with_idx' if args.with_idx else ''} query_size={args.queries}/GPU on {world}x MI355X",
-                           "k": args.topk, "avg_rounds": float(np.mean(topk_out["rounds"])), "batch": eng.get_batch()},
-                "phases": {k: v for k, v in tm.items() if k.endswith("_ms")}}))
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                "dtype": DTYPE, "data": "synthetic",
+                "config": {"workload": f"{args.graph}-sized R-MAT (n={n}, m={m}) topk k={args.topk} --opt"
+                                       f"{' --with_idx' if args.with_idx else ''} eps={args.epsilon} {qdesc} on {world}x MI355X, "
+                                       f"RCCL all-gather of the [Q, k] lists inside the timed region",
+                           "graph": args.graph, "n": n, "m": m, "k": args.topk, "avg_rounds": rounds_all[0] / max(1.0, rounds_all[1]),
+                           "batch": eng.get_batch(), "sharding": shard, "device": arch, "cus": cus,
+                           "gather_bytes_per_step": int(q_step_total * args.topk * 12)},
+                "phases": {k: v for k, v in tm.items() if k.endswith("_ms")},
+                "setup_s": {"graph": t_graph, "upload": t_upload, "index_build": t_idx}}))
         eng.close()
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
     # sanity inside the bench: every query conserved mass exactly, none was skipped
     assert len(last) == len(mine)
     assert all(s["ppr_sum_fix"] == 1 << 62 for s in last), "mass not conserved"
@@ -214,35 +332,39 @@ def main():
         out = {
             "metric": "SSPPR queries/sec at eps=0.5", "value": qps, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64 fixed-point 2^-62 (f64 at the boundary)", "data": "synthetic",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {
                 "workload": f"{args.graph}-sized R-MAT (n={n}, m={m}, dangling={args.dangling}) eps={args.epsilon} "
-                            f"query_size={args.queries}/GPU, fora push + "
+                            f"{qdesc}, fora push + "
                             f"{'indexed' if args.with_idx else 'online Philox'} walks"
                             f"{' --opt' if args.opt else ''}{' --balanced' if args.balanced else ''} on {world}x MI355X",
-                "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "query_size_per_gpu": args.queries,
+                "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "queries_per_step": int(tot[0]),
                 "with_idx": bool(args.with_idx), "opt": bool(args.opt), "balanced": bool(args.balanced), "batch": eng.get_batch(),
-                "sharding": f"sources i mod {world}", "non_dangling_sources": int(tot[1]),
+                "sharding": shard, "non_dangling_sources": int(tot[1]),
                 "rmax": rmax, "omega": omega, "device": arch, "cus": cus,
             },
         }
         q_timed = len(mine) * args.steps  # queries this rank ran in the timed region
-        cpu, p_fifo, e_fifo = (None, None, None)
+        p_fifo = e_fifo = None
+        counts_from = "GPU schedule (no CPU sample)"
+        g = None
         if not args.no_cpu:
             import oracle_lib as O
             g = O.Graph(n, m, row_ptr, col)
-            if world == 1:  # the CPU baseline is timed at N = 1 only
+            per_query_guess = 0.35e-6 * m  # one FIFO push is a few sweeps of the edge list on one core
+            if world == 1 and per_query_guess <= args.cpu_seconds:  # the CPU baseline is timed at N = 1 only
                 index = None
                 if args.with_idx:
                     rw, off, cnt = eng.get_index()
                     index = (rw, off, cnt)
                 cpu, p_fifo, e_fifo = cpu_baseline(g, mine, rmax, omega, args, index)
+                counts_from = "sequential FIFO oracle (CPU), same sources"
                 out["cpu_baseline"] = cpu
                 threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
                 if threads > 1:
                     out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
-            else:  # N > 1: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
+            elif per_query_guess <= 5.0:  # N > 1: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
                 t1 = time.perf_counter()
                 pp = pr = pn = 0
                 for s in mine[:64]:
@@ -251,9 +373,14 @@ def main():
                     if time.perf_counter() - t1 > 5.0:
                         break
                 p_fifo, e_fifo = pp / max(1, pn), pr / max(1, pn)
+                counts_from = "sequential FIFO oracle (CPU), same sources"
+            else:
+                out["cpu_baseline"] = None
+                out["cpu_baseline_note"] = (f"one oracle query on this graph needs about {per_query_guess:.0f} s of one core, more than "
+                                            f"--cpu-seconds {args.cpu_seconds:g}; raise it to time the CPU port here")
         if not args.no_accuracy and not args.opt:
-            out["accuracy"] = accuracy(eng, mine, n, args, np)
-        if world == 1 and not args.balanced and not args.no_variants:
+            out["accuracy"] = accuracy(eng, g, mine, n, m, args, np)
+        if world == 1 and not args.balanced and not args.no_variants and args.graph in ("webstanford", "small", "tiny"):
             # the reference's other way to run the same query path (README.md:135): --balanced; not the headline value
             eng.set_balanced(True, start_scale=args.balanced_start)
             eng.query(mine, with_idx=args.with_idx, want_ppr=False)
@@ -279,23 +406,22 @@ def main():
             p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
             launches = tm["push_expand_launches"]
             bucketed = tm["push_accum_launches"] > 0
-            fused = bucketed and tm["push_pop_launches"] == 0
-            # bucketed push: one level is the kernel PAIR k_pushq_popbin + k_accum<false> (same launch count);
-            # the pop is fused into the first, so the pair carries the whole push: 52 B per pop + 24 B per edge
-            # relaxation of the sequential FIFO oracle, credited once against the sum of both kernels' durations
-            alg_bytes = (24.0 * e_unit + (52.0 * p_unit if fused else 0.0)) * q_timed
+            # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
+            # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
+            # relaxation, credited once against the sum of both kernels' durations
+            alg_bytes = (24.0 * e_unit + (52.0 * p_unit if bucketed else 0.0)) * q_timed
             step_ms = tm["push_expand_ms"] + tm["push_accum_ms"]
             avg_ms = step_ms / launches
             achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
             traffic = None
             traffic_note = None
-            if os.path.exists(args.traffic):
+            tpath = args.traffic or os.path.join(ROOT, "profiles", f"pmc_traffic_{args.graph}{'_idx' if args.with_idx else ''}.json")
+            if os.path.exists(tpath):
                 # HBM-side bytes per launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE and
                 # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
                 # coalesced reads by up to 2x on gfx950 -- these kernels read 4-12 B per lane, reported raw)
-                pmc = json.load(open(args.traffic))
-                prefixes = (["fora::k_pushq_popbin", "fora::k_accum<false>", "fora::k_push_tail"] if fused else
-                            ["fora::k_pushq_bin", "fora::k_accum<false>"] if bucketed else ["fora::k_push_expand"])
+                pmc = json.load(open(tpath))
+                prefixes = (["fora::k_pushq_bin", "fora::k_accum<false>", "fora::k_push_tail"] if bucketed else ["fora::k_push_expand"])
                 keys = [k for k in pmc if any(k.startswith(p) for p in prefixes)]
                 lead = [k for k in pmc if k.startswith(prefixes[0])]
                 if lead and all("FETCH_SIZE_bytes_total" in pmc[k] for k in keys):
@@ -306,23 +432,22 @@ def main():
                     traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
                                   for k in keys) / max(1, n_launch)
                     traffic_note = pmc.get("_note")
-            by_kernel = {("k_pushq_popbin" if fused else "k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / launches}
+            by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / launches}
             if bucketed:
                 by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
             if tm["push_pop_launches"]:
-                by_kernel["k_pushq_pop" if bucketed else "k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
+                by_kernel["k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": ("fora::k_pushq_popbin + fora::k_accum<false> (one level of the push; k_push_tail finishes the small levels)" if fused else
-                           "fora::k_pushq_bin + fora::k_accum<false> (expand step of one level)" if bucketed
-                           else "fora::k_push_expand"),
+                "kernel": ("fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
+                           if bucketed else "fora::k_push_expand"),
                 "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
-                "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation of the sequential FIFO oracle" if fused
-                                     else "24 B per edge relaxation of the sequential FIFO oracle",
+                "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation" if bucketed else "24 B per edge relaxation",
+                "algorithmic_counts": counts_from,
                 "fifo_relaxations_per_query": e_unit, "fifo_pops_per_query": p_unit,
-                "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed),
+                "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed), "gpu_pops_per_query": tm["pops"] / max(1, q_timed),
                 "push_total": {  # all push kernels against 52*P + 24*E
                     "achieved": (52.0 * p_unit + 24.0 * e_unit) * q_timed
                                 / ((step_ms + tm["push_pop_ms"]) * 1e-3) / 1e9,
@@ -336,14 +461,15 @@ def main():
             "walks": tm["walks"], "walk_steps": tm["walk_steps"],
             "walks_per_s": tm["walks"] / max(1e-9, tm["walk_ms"] * 1e-3),
             "walk_algorithmic_GBps": walk_bytes / max(1e-9, tm["walk_ms"] * 1e-3) / 1e9,
-            "index_build_s": t_idx,
+            "index_build_s": t_idx, "graph_s": t_graph, "upload_s": t_upload,
         }
         print(json.dumps(out))
     eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -116,7 +116,7 @@ struct fora_ctx {
     uint32_t *d_bk_w = nullptr, *d_bk_count = nullptr;
     uint64_t *d_bk_inc = nullptr;
     uint64_t segq_cap = 0;
-    uint32_t bk_cap = 0;
+    uint32_t bk_cap = 0, sub = 0; // capacity of one sub-bucket; sub-buckets per (slot, bin) = producer workgroups per slot
     uint32_t *d_wit_count = nullptr; // [B * CSTRIDE]
     uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
@@ -248,9 +248,14 @@ static uint32_t want_bk_cap_wide(const fora_ctx *c) { // push messages only (wal
     return 196608; // also holds the indexed walk results (~omega*rsum/nbins per bucket)
 }
 
-struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32_t bk_cap; uint64_t segq_cap; bool binned; };
+struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32_t bk_cap, sub; uint64_t segq_cap; bool binned; };
 // (the wide / narrow choice changes bk_cap, which forces a re-plan of the workspace)
-static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
+// sub-buckets per (slot, bin) = producer workgroups per slot (Dev::bk_w): ~16 k producer workgroups per launch
+static uint32_t want_sub(const fora_ctx *c, int slots) {
+    if (c->opt_.xb > 0) return (uint32_t)std::min<int64_t>(c->opt_.xb, MAX_SUB);
+    return (uint32_t)std::min(MAX_SUB, std::max(16, 16384 / std::max(1, slots)));
+}
+static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
     WsPlan p{};
     const uint64_t n = (uint64_t)c->n;
     p.binned = want_binned(c);
@@ -261,10 +266,17 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint) {
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
         p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c)) : p.nbins;
-        p.bk_cap = (uint32_t)std::min<uint64_t>((uint64_t)(want_wide(c) ? want_bk_cap_wide(c) : want_bk_cap(c)) * c->bk_scale, 1u << 28);
+        p.sub = want_sub(c, slots);
+        { // capacity of one sub-bucket: the bucket's capacity over its sub-buckets (+25 % for uneven producers); the
+          // `bkcap` option (tests) sets it directly
+            const uint64_t total = (uint64_t)(want_wide(c) ? want_bk_cap_wide(c) : want_bk_cap(c));
+            uint64_t cap = c->opt_.bkcap > 0 ? total : (total + total / 4 + p.sub - 1) / p.sub;
+            cap = std::min<uint64_t>(cap * c->bk_scale, 1u << 28);
+            p.bk_cap = (uint32_t)((cap + 15) & ~15ull);
+        }
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * 12 + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -311,7 +323,7 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
-    const WsPlan p = plan_workspace(c, omega_hint);
+    WsPlan p = plan_workspace(c, omega_hint, 1024); // bytes per slot hardly depend on the slot count (sub-bucket rounding)
     int B = c->batch_req > 0 ? c->batch_req : 0;
     if (B == 0) {
         size_t fr = 0, tot = 0;
@@ -322,8 +334,14 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     B = std::max(1, B);
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
     const uint64_t n = (uint64_t)c->n;
+    if (c->B >= B) { // an existing workspace with enough slots and the same layout is kept as it is
+        const WsPlan pe = plan_workspace(c, omega_hint, c->B);
+        if (c->binned == pe.binned && c->pbins == pe.pbins && c->seg_cap * sizeof(PushSeg) >= (uint64_t)c->B * pe.scratch && c->wit_cap >= pe.wits &&
+            c->bk_cap == pe.bk_cap && c->sub == pe.sub)
+            return ensure_row_split(c, pe.nbins, pe.pbins);
+    }
+    p = plan_workspace(c, omega_hint, B);
     const uint64_t scratch = (uint64_t)B * p.scratch;
-    if (c->B >= B && c->binned == p.binned && c->pbins == p.pbins && c->seg_cap * sizeof(PushSeg) >= scratch && c->wit_cap >= p.wits && c->bk_cap == p.bk_cap) return ensure_row_split(c, p.nbins, p.pbins);
     free_workspace(c);
     const uint64_t slab = (uint64_t)B * n;
     HIPCHK(c, hipMalloc(&c->d_residue, slab * 8));
@@ -339,9 +357,9 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
-        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.bk_cap * 4));
-        HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.bk_cap * 8));
-        HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * 4 * CSTRIDE));
+        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 4));
+        HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 8));
+        HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * p.sub * 4));
         HIPCHK(c, hipHostMalloc(&c->h_flc, (size_t)FLC_RING * B * 4 * CSTRIDE));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
@@ -357,7 +375,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipHostMalloc(&c->h_qs_pin, (size_t)B * sizeof(QState)));
     HIPCHK(c, hipHostMalloc(&c->h_steps_pin, sizeof(unsigned long long)));
     c->B = B;
-    c->binned = p.binned; c->nbins = p.nbins; c->pbins = p.pbins; c->bk_cap = p.bk_cap; c->segq_cap = p.segq_cap;
+    c->binned = p.binned; c->nbins = p.nbins; c->pbins = p.pbins; c->bk_cap = p.bk_cap; c->sub = p.sub; c->segq_cap = p.segq_cap;
     if (int rs = ensure_row_split(c, p.nbins, p.pbins)) return rs;
     c->wl_cap = slab;
     c->seg_cap = scratch / sizeof(PushSeg);
@@ -403,7 +421,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.stamps = c->d_stamps;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
     d.ov_count[0] = c->d_ov_count; d.ov_count[1] = c->d_ov_count ? c->d_ov_count + (size_t)c->B * CSTRIDE : nullptr;
-    d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap;
+    d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap; d.sub = c->sub;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;
 }
@@ -465,8 +483,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     int rc = FORA_OK;
     int L = 0;
     const int nq = d.nq;
-    unsigned xb = (unsigned)std::min(1024, std::max(16, 16384 / std::max(1, nq))); // blocks per slot; ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
-    if (c->opt_.xb > 0) xb = (unsigned)c->opt_.xb;
+    const unsigned xb = c->binned ? c->sub : 1u; // producer workgroups per slot = sub-buckets per bucket (Dev::bk_w); ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
     // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
     const uint32_t tail_max = (uint32_t)std::max<int64_t>(0, c->opt_.tail);
     bool past_peak = c->opt_.tail_always == 1; // tests: do not wait for the frontier to have been large first
@@ -569,7 +586,7 @@ int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, doubl
 int reset_binned_counters(fora_ctx *c) {
     if (!c->binned) return FORA_OK;
     HIPCHK(c, hipMemsetAsync(c->d_fl_count, 0, (size_t)c->B * 2 * 4 * CSTRIDE, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * c->sub * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
     return FORA_OK;
 }
@@ -593,20 +610,21 @@ enum { RUN_PUSH_ONLY = 1 };
 // refinement launches after k_walk_alloc: indexed walks, online walks, and the accumulate of their results
 void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t round, int nzh) {
     const dim3 wg(walk_grid_x(c, nq), nq);
+    const dim3 wgs(c->binned ? c->sub : 1u, nq); // kernels that fill buckets: one workgroup per sub-bucket (Dev::bk_w)
     int h = ev_begin(c, 3);
     if (with_idx) {
         if (!c->binned) hipLaunchKernelGGL(k_walk_idx<1>, wg, dim3(BLOCK), 0, c->stream, d);
-        else if (!d.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, wg, dim3(BLOCK), 0, c->stream, d);
+        else if (!d.wide) hipLaunchKernelGGL(k_walk_idx<MAX_BINS>, wgs, dim3(BLOCK), 0, c->stream, d);
         else
             for (int lo = 0; lo < c->nbins; lo += c->pbins) { // buckets are reused pass by pass
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
-                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wg, dim3(BLOCK), 0, c->stream, dp);
+                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BLOCK), 0, c->stream, dp);
                 hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
             }
     }
-    hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, c->binned && !d.wide ? wgs : wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
     ev_end(c, h);
     if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets
         h = ev_begin(c, 7);

@@ -44,6 +44,7 @@ constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN
 // slabs in L2 (accumulate kernels -1 %)
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
+constexpr int MAX_SUB = 128; // sub-buckets per (slot, bin) bucket = producer workgroups per slot
 // Narrow layout: a walk result travels as ONE 64-bit word, node id (< 2^20) | weight << 20 (weights are r / num_s_rw,
 // about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
 constexpr int WPACK_SHIFT = 20;
@@ -136,10 +137,17 @@ struct Dev {
     unsigned long long *stamps; // diagnostic builds (-DFORA_STAMPS): cycles per kernel phase, [0..15] bin kernel, [16..31] accumulate
     int32_t pop_next;       // k_accum<false>: pop the crossing nodes for the next level (0 on the last level of a capped run)
     uint64_t segq_cap;      // = n: a frontier holds each node at most once
-    uint32_t *bk_w;         // [slot][bin][bk_cap] target node of a pending increment
-    uint64_t *bk_inc;       // [slot][bin][bk_cap] its value
-    uint32_t *bk_count;     // [slot][bin]
-    uint32_t bk_cap;
+    // Message buckets.  Every (slot, bin) bucket is cut into `sub` sub-buckets, one per producer workgroup of the slot
+    // (the bin kernel and the walk kernels launch exactly `sub` workgroups per slot): workgroup x appends only to
+    // sub-bucket x and keeps its fill counters in LDS, so an append costs no global atomic at all -- with hundreds of
+    // bins a 2048-edge chunk holds 2-4 messages per bin, and one reservation atomic per (chunk, bin) ran the wide bin
+    // kernel into the chip's ~23 G/s memory-side atomic rate.  The counters are loaded when a producer kernel starts
+    // and stored when it ends; k_accum reads the `sub` counts of its bucket and zeroes them.
+    uint32_t *bk_w;         // [slot][bin][sub][bk_cap] target node of a pending increment
+    uint64_t *bk_inc;       // [slot][bin][sub][bk_cap] its value
+    uint32_t *bk_count;     // [slot][bin][sub]
+    uint32_t bk_cap;        // capacity of ONE sub-bucket
+    uint32_t sub;           // sub-buckets per bucket (<= MAX_SUB)
     // messages that found their bucket full (rare; capacity is a tuning knob): per-slot overflow list,
     // folded in by k_accum.  Count is double-buffered by level parity (zeroed one level later).
     uint32_t *ov_w;         // [slot][ov_cap]
@@ -520,8 +528,8 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 //   k_pushq_bin     frontier (per-slot list, node-ordered inside every bin's run) -> the pop arithmetic
 //                   (alpha of the residue to the reserve slab, increment per out-edge) one entry per
 //                   lane, then increments binned by target range: per 2048-edge chunk an LDS
-//                   histogram, ONE global atomic per (chunk, bin) to reserve bucket space, then
-//                   bin-sorted message stores
+//                   histogram, space in the workgroup's own sub-bucket of every bin (a counter in LDS, no
+//                   global atomic), then bin-sorted message stores
 //   k_accum<false>  one workgroup per (slot, bin): ds_add_u64 every message into 64 KiB of LDS
 //                   accumulators, then sweep them: one plain RMW per touched node (the
 //                   workgroup owns that residue range); a node that crosses its threshold has
@@ -533,9 +541,9 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // grid = (X, nq).  A block takes 256 frontier entries (node, residue) of a slot and pops them (residue -> reserve, increment;
 // algo.h:983-1002; row start, increment, degree prefix sum into LDS).  Then it bins their concatenated out-edges in
 // chunks of BIN_EPT * BLOCK: each lane gathers BIN_EPT consecutive edges (all loads issued before any is waited
-// for), an LDS histogram over the target bins gives every message its rank, ONE global atomic per (chunk, bin)
-// reserves bucket space -- in flight while the messages are staged bin-sorted in LDS -- and the stage is written out
-// in runs.  No slice list is materialised: a narrow message names the frontier position of its source node
+// for), an LDS histogram over the target bins gives every message its rank, the workgroup's LDS fill counters give the
+// chunk its place in the workgroup's own sub-buckets (Dev::bk_w: no global atomic), the messages are staged bin-sorted
+// in LDS and the stage is written out in runs.  No slice list is materialised: a narrow message names the frontier position of its source node
 // (increment table `inc_tab`), a wide one carries the increment.  Measured and dropped: gathering with
 // consecutive lanes on consecutive edges through an LDS address table, carrying rowinfo in the frontier entry, and
 // loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
@@ -557,6 +565,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     __shared__ uint32_t s_pref[BLOCK + 1];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_fill[NB]; // messages this workgroup has put into its sub-bucket of every bin
     // stage: ONE word per message.  narrow: (local target << SEG_BITS) | frontier position, its bin in s_bin;
     // wide: local target (13 bits) | source entry inside the tile (8) | bin (10)
     __shared__ uint32_t s_msg[CHUNK];
@@ -566,10 +575,15 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const uint64_t fbase = (uint64_t)q * d.segq_cap;
     const uint32_t *in = d.fl[par] + slab;
     uint64_t *incs = d.inc_tab[par] + fbase;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
+    const uint32_t sub = d.sub; // == gridDim.x: this workgroup owns sub-bucket blockIdx.x of every bin of the slot
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + blockIdx.x;                  // count of bin b: bkc[b * sub]
+    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap;             // sub-bucket of bin b: bk0 + b * sub * bk_cap
+    const uint64_t bstride = (uint64_t)sub * d.bk_cap;
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) {
+        s_cnt[i] = 0;
+        s_fill[i] = i < bin_cnt ? bkc[(uint64_t)i * sub] : 0;
+    }
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
     STAMP_DECL
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < count; tbase += gridDim.x * BLOCK) {
@@ -638,12 +652,10 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             __syncthreads();
             STAMP(1);
             uint32_t staged; // messages of this chunk that belong to the pass's bins
-            // reserve bucket space (ONE global atomic per (chunk, bin), left in flight) and lay the bins out in the
-            // LDS stage: lane t owns bins t*PER .. t*PER+PER-1
-            constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
-            uint32_t c[PER], gb[PER];
-            {
-                uint32_t mine = 0;
+            { // take sub-bucket space (a counter in LDS, no atomic) and lay the bins out in the LDS stage:
+              // lane t owns bins t*PER .. t*PER+PER-1
+                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+                uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
@@ -656,12 +668,13 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
                     const uint32_t b = threadIdx.x * PER + j;
-                    gb[j] = 0;
                     if (b < (uint32_t)NB) {
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) {
-                            gb[j] = atomicAdd(&bkc[b * CSTRIDE], c[j]);
+                            const uint32_t f = s_fill[b];
+                            s_base[b] = f;
+                            s_fill[b] = f + c[j];
                             s_cnt[b] = 0;
                         }
                     }
@@ -679,9 +692,6 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     else { s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own); s_bin[sp] = (uint8_t)b; }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < PER; j++) // the reservations have had the staging to come back
-                if (c[j]) s_base[threadIdx.x * PER + j] = gb[j];
             __syncthreads();
             STAMP(3);
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
@@ -691,7 +701,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                 else { b = s_bin[m]; sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
                 const uint32_t pos = s_base[b] + (m - s_lofs[b]);
                 if (pos < d.bk_cap) {
-                    const uint64_t at = bk0 + (uint64_t)b * d.bk_cap + pos;
+                    const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
                     if (WIDE) { d.bk_w[at] = local; d.bk_inc[at] = s_inc[sidx]; }
                     else d.bk_w[at] = e;
                 } else { // bucket full: park the increment in the slot's overflow list
@@ -707,6 +717,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
         __syncthreads();
         STAMP(5);
     }
+    for (uint32_t i = threadIdx.x; i < bin_cnt; i += BLOCK) bkc[(uint64_t)i * sub] = s_fill[i];
     STAMP_FLUSH(0);
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
@@ -865,69 +876,85 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint32_t s_gbase;
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
     __shared__ uint32_t s_nlist;
+    __shared__ uint32_t s_scnt[MAX_SUB], s_total;
     const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
     const int b = d.bin_lo + lb;
     const int par = L & 1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
-    const uint32_t bi = (uint32_t)q * d.pbins + lb;
-    uint32_t cnt = d.bk_count[(uint64_t)bi * CSTRIDE];
-    if (cnt > d.bk_cap) cnt = d.bk_cap; // the excess is in the overflow list (push) / went by direct atomics (walks)
+    const uint32_t sub = d.sub;
+    const uint64_t bi = (uint64_t)q * d.pbins + lb;
+    // the bucket's sub-buckets: counts (clamped: the excess is in the overflow list (push) / went by direct atomics (walks))
+    if (threadIdx.x < 64) {
+        uint32_t t = 0;
+        for (uint32_t x = threadIdx.x; x < sub; x += 64) {
+            uint32_t c = d.bk_count[bi * sub + x];
+            if (c) d.bk_count[bi * sub + x] = 0;
+            if (c > d.bk_cap) c = d.bk_cap;
+            s_scnt[x] = c;
+            t += c;
+        }
+        t = (uint32_t)wave_sum((uint64_t)t);
+        if (threadIdx.x == 0) { s_total = t; s_nlist = 0; }
+    }
     const uint32_t s = (uint32_t)d.src[q];
     const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
     uint64_t *target = TO_PPR ? d.ppr : d.residue;
-    if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        d.bk_count[(uint64_t)bi * CSTRIDE] = 0;
-        if (dm) d.qs[q].dang[par] = 0;
-    }
+    const uint32_t cnt = s_total;
+    if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
     uint32_t ovn = TO_PPR ? 0 : d.ov_count[par][q * CSTRIDE];
     if (ovn > d.ov_cap) ovn = d.ov_cap;
     if (cnt == 0 && dm == 0 && ovn == 0) return;
     uint32_t *fl_next = d.fl[par ^ 1] + slab;
     uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
     uint32_t *flc_next = &d.fl_count[par ^ 1][q * CSTRIDE];
-    const uint64_t bk0 = (uint64_t)bi * d.bk_cap;
+    const uint64_t bk0 = bi * sub * d.bk_cap; // sub-bucket x starts at bk0 + x * bk_cap
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
     const uint64_t *itab = TO_PPR ? nullptr : d.inc_tab[par] + (uint64_t)q * d.segq_cap;
+    const bool gather = !TO_PPR && !d.wide;
+    const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
     if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
-        // node range and the level's pops are done, so nothing else touches these words)
-        const uint32_t total = cnt + (dm ? 1 : 0);
-        for (uint32_t i0 = 0; i0 < total; i0 += ACC_THREADS) {
-            const uint32_t i = i0 + threadIdx.x;
-            bool cross = false;
-            uint32_t w = 0;
-            uint64_t inc = 0;
-            if (i < cnt) {
-                if (TO_PPR && !d.wide) { // narrow walk results: one packed word, node id | weight << WPACK_SHIFT
-                    const uint64_t pk = d.bk_inc[bk0 + i];
-                    w = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
-                    inc = pk >> WPACK_SHIFT;
-                } else w = d.bk_w[bk0 + i];
-                if (TO_PPR && d.wide) inc = d.bk_inc[bk0 + i];
-                else if (TO_PPR) {}
-                else if (d.wide) { inc = d.bk_inc[bk0 + i]; w = node0 + w; }
-                else {
-                    inc = itab[w & ((1u << SEG_BITS) - 1)];
-                    w = node0 + (w >> SEG_BITS);
+        // node range and the level's pops are done, so nothing else touches these words).  Wave w takes sub-buckets
+        // w, w + NW, ...
+        for (uint32_t x = wid; x <= sub; x += NW) {
+            const uint32_t n_x = x < sub ? s_scnt[x] : (dm ? 1u : 0u); // x == sub: the dangling mass, one more "message"
+            const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
+            for (uint32_t i0 = 0; i0 < n_x; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool cross = false;
+                uint32_t w = 0;
+                uint64_t inc = 0;
+                if (i < n_x && x < sub) {
+                    if (packed) { // narrow walk results: one packed word, node id | weight << WPACK_SHIFT
+                        const uint64_t pk = d.bk_inc[at0 + i];
+                        w = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
+                        inc = pk >> WPACK_SHIFT;
+                    } else w = d.bk_w[at0 + i];
+                    if (TO_PPR && d.wide) inc = d.bk_inc[at0 + i];
+                    else if (TO_PPR) {}
+                    else if (d.wide) { inc = d.bk_inc[at0 + i]; w = node0 + w; }
+                    else {
+                        inc = itab[w & ((1u << SEG_BITS) - 1)];
+                        w = node0 + (w >> SEG_BITS);
+                    }
+                } else if (i < n_x) { w = s; inc = dm; }
+                if (inc) {
+                    const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
+                    if (!TO_PPR) {
+                        const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                        cross = old < thr && old + inc >= thr; // increments are positive: exactly one add crosses
+                    }
                 }
-            } else if (i == cnt && dm) { w = s; inc = dm; }
-            if (inc) {
-                const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
                 if (!TO_PPR) {
-                    const uint64_t thr = node_thr(d.t1, d.deg[w]);
-                    cross = old < thr && old + inc >= thr; // increments are positive: exactly one add crosses
-                }
-            }
-            if (!TO_PPR) {
-                const unsigned long long mask = __ballot(cross);
-                if (mask) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_nlist, (uint32_t)__popcll(mask));
-                    base = __shfl(base, 0);
-                    if (cross) s_list[base + __popcll(mask & ((1ull << lane) - 1))] = w; // <= tiny_max + 1 <= 1024 entries
+                    const unsigned long long mask = __ballot(cross);
+                    if (mask) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nlist, (uint32_t)__popcll(mask));
+                        base = __shfl(base, 0);
+                        if (cross) s_list[base + __popcll(mask & ((1ull << lane) - 1))] = w; // <= tiny_max + 1 <= 1024 entries
+                    }
                 }
             }
         }
@@ -947,45 +974,37 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         return;
     } else {
     STAMP_DECL
-    // messages: ACC_UNROLL per lane and iteration, all loads BRANCH-FREE (clamped index, masked afterwards).
-    // With an `if (i < cnt)` around each load hipcc puts every dependent increment gather behind its own
-    // s_waitcnt vmcnt(0): eight serialized round trips per iteration instead of two.  The message words of an
-    // iteration are requested one iteration ahead; the first ones travel while the accumulators are zeroed.
-    constexpr int ACC_UNROLL = 8;
-    const bool gather = !TO_PPR && !d.wide;
-    const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
-    uint32_t mw[ACC_UNROLL];
-#pragma unroll
-    for (int k = 0; k < ACC_UNROLL; k++) {
-        const uint32_t i = k * ACC_THREADS + threadIdx.x;
-        mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
-    }
     for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
     __syncthreads();
     STAMP(16);
-    for (uint32_t i0 = 0; i0 < cnt; i0 += ACC_THREADS * ACC_UNROLL) {
-        uint64_t mi[ACC_UNROLL];
-        uint32_t lc[ACC_UNROLL];
-#pragma unroll
-        for (int k = 0; k < ACC_UNROLL; k++) {
-            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[bk0 + (i < cnt ? i : 0)]);
-            lc[k] = gather ? mw[k] >> SEG_BITS : mw[k];
-        }
-        if (i0 + ACC_THREADS * ACC_UNROLL < cnt) {
+    // messages: wave w takes sub-buckets w, w + NW, ...; ACC_UNROLL x 64 messages per iteration, all loads BRANCH-FREE
+    // (clamped index, masked afterwards).  With an `if (i < cnt)` around each load hipcc puts every dependent increment
+    // gather behind its own s_waitcnt vmcnt(0): serialized round trips instead of two per iteration.
+    constexpr int ACC_UNROLL = 4;
+    for (uint32_t x = wid; x < sub; x += NW) {
+        const uint32_t n_x = s_scnt[x];
+        const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
+        for (uint32_t i0 = 0; i0 < n_x; i0 += 64 * ACC_UNROLL) {
+            uint32_t mw[ACC_UNROLL];
+            uint64_t mi[ACC_UNROLL];
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
-                const uint32_t i = i0 + (ACC_UNROLL + k) * ACC_THREADS + threadIdx.x;
-                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[bk0 + (i < cnt ? i : 0)]);
+                const uint32_t i = i0 + k * 64 + lane;
+                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[at0 + (i < n_x ? i : 0)]);
             }
-        }
 #pragma unroll
-        for (int k = 0; k < ACC_UNROLL; k++) {
-            const uint32_t i = i0 + k * ACC_THREADS + threadIdx.x;
-            uint32_t local = lc[k];
-            uint64_t inc = mi[k];
-            if (packed) { local = (uint32_t)inc; inc >>= WPACK_SHIFT; }
-            if (i < cnt && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
+            for (int k = 0; k < ACC_UNROLL; k++) {
+                const uint32_t i = i0 + k * 64 + lane;
+                mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at0 + (i < n_x ? i : 0)]);
+            }
+#pragma unroll
+            for (int k = 0; k < ACC_UNROLL; k++) {
+                const uint32_t i = i0 + k * 64 + lane;
+                uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
+                uint64_t inc = mi[k];
+                if (packed) { local = (uint32_t)inc; inc >>= WPACK_SHIFT; }
+                if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
+            }
         }
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
@@ -1579,13 +1598,14 @@ struct WaveStage {
     uint64_t *pk;    // [STAGE]
     uint32_t *bcnt;  // [MAX_BINS]
     uint32_t *bbase; // [MAX_BINS]
+    uint32_t *fill;  // [MAX_BINS] of the WORKGROUP: messages in its sub-bucket of every bin (see Dev::bk_w)
     uint32_t count;  // wave-uniform
 };
 __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) {
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
+    const uint64_t bk0 = ((uint64_t)q * d.pbins * d.sub + blockIdx.x) * d.bk_cap; // sub-bucket blockIdx.x of bin b: + b * sub * bk_cap
+    const uint64_t bstride = (uint64_t)d.sub * d.bk_cap;
     st.bcnt[lane] = 0;
     st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -1602,12 +1622,13 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    { // bucket space: ONE global atomic per (flush, bin); and the bins' offsets inside the wave's stage
+    { // space in the workgroup's sub-buckets: one LDS atomic per (flush, bin) on the workgroup's fill counters; and the
+      // bins' offsets inside the wave's stage
         const uint32_t c0 = lane < d.nbins ? st.bcnt[lane] : 0, c1 = lane + 64 < d.nbins ? st.bcnt[lane + 64] : 0;
         uint32_t t0, t1;
         const uint32_t o0 = wave_excl_scan(c0, t0), o1 = wave_excl_scan(c1, t1);
-        if (c0) st.bbase[lane] = atomicAdd(&bkc[lane * CSTRIDE], c0);
-        if (c1) st.bbase[lane + 64] = atomicAdd(&bkc[(lane + 64) * CSTRIDE], c1);
+        if (c0) st.bbase[lane] = atomicAdd(&st.fill[lane], c0);
+        if (c1) st.bbase[lane + 64] = atomicAdd(&st.fill[lane + 64], c1);
         st.bcnt[lane] = o0;           // from here on: first stage slot of the bin
         st.bcnt[lane + 64] = t0 + o1;
     }
@@ -1626,7 +1647,7 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
             const uint32_t dd = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
             const uint32_t b = dd >> BIN_SHIFT;
             const uint32_t pos = st.bbase[b] + (m - st.bcnt[b]);
-            if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * d.bk_cap + pos] = pk;
+            if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * bstride + pos] = pk;
             else atomicAdd((unsigned long long *)&d.ppr[slab + dd], (unsigned long long)(pk >> WPACK_SHIFT)); // bucket full
         }
     }
@@ -1650,9 +1671,11 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
 #define WAVE_STAGE_DECL(st)                                                                         \
     __shared__ uint64_t st##_pk[BLOCK / 64][STAGE];                                                 \
     __shared__ uint32_t st##_bcnt[BLOCK / 64][MAX_BINS], st##_bbase[BLOCK / 64][MAX_BINS];         \
+    __shared__ uint32_t st##_fill[MAX_BINS];                                                        \
     WaveStage st;                                                                                   \
     st.pk = st##_pk[threadIdx.x >> 6];                                                              \
-    st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6]; st.count = 0;
+    st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6];                 \
+    st.fill = st##_fill; st.count = 0;
 
 // ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
 // are read from rw_idx.  Streaming gather; grid = (X, nq).  With the bucketed layouts the results
@@ -1664,6 +1687,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_pref[BLOCK + 1], s_w[4];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_fill[NB]; // messages this workgroup has put into its sub-bucket of every bin (see Dev::bk_w)
     constexpr bool BINNED = NB > 1;
     constexpr bool PACK = BINNED && NB <= MAX_BINS; // narrow: one word per result, node id | weight << WPACK_SHIFT
     __shared__ uint32_t s_msg[BINNED && !PACK ? BLOCK * EPT : 1], s_dst[NB > 1 ? BLOCK * EPT : 1];
@@ -1673,10 +1697,14 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     if (!nitems) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * CSTRIDE;
-    const uint64_t bk0 = (uint64_t)q * d.pbins * d.bk_cap;
+    const uint32_t sub = d.sub; // BINNED: == gridDim.x, this workgroup owns sub-bucket blockIdx.x of every bin of the slot
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + blockIdx.x;      // count of bin b: bkc[b * sub]
+    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap; // sub-bucket of bin b: bk0 + b * sub * bk_cap
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
-    if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) s_cnt[i] = 0;
+    if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) {
+        s_cnt[i] = 0;
+        s_fill[i] = i < bin_cnt ? bkc[(uint64_t)i * sub] : 0;
+    }
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
@@ -1763,8 +1791,10 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                     if (b < (uint32_t)NB) {
                         s_lofs[b] = pre2;
                         pre2 += c[j];
-                        if (c[j]) {
-                            s_base[b] = atomicAdd(&bkc[b * CSTRIDE], c[j]); // ONE global atomic per (chunk, bin)
+                        if (c[j]) { // space in the workgroup's own sub-bucket: a counter in LDS, no global atomic
+                            const uint32_t f = s_fill[b];
+                            s_base[b] = f;
+                            s_fill[b] = f + c[j];
                             s_cnt[b] = 0;
                         }
                     }
@@ -1779,22 +1809,24 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                     const uint32_t sp = s_lofs[b] + rank[k];
                     if (PACK) s_val[sp] = (uint64_t)dest[k] | (wgt[k] << WPACK_SHIFT);
                     else { s_msg[sp] = dest[k]; s_val[sp] = wgt[k]; }
-                    s_dst[sp] = pos < d.bk_cap ? b * d.bk_cap + pos : 0xFFFFFFFFu;
+                    s_dst[sp] = pos < d.bk_cap ? b : 0xFFFFFFFFu; // bin; the slot inside the sub-bucket follows from the stage position
                     if (pos >= d.bk_cap) // bucket full: direct atomic, same sum
                         atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
                 }
             }
             __syncthreads();
             for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) {
-                const uint32_t dst = s_dst[m];
-                if (dst != 0xFFFFFFFFu) {
-                    if (!PACK) d.bk_w[bk0 + dst] = s_msg[m];
-                    d.bk_inc[bk0 + dst] = s_val[m];
+                const uint32_t bb = s_dst[m];
+                if (bb != 0xFFFFFFFFu) {
+                    const uint64_t at = bk0 + (uint64_t)bb * sub * d.bk_cap + s_base[bb] + (m - s_lofs[bb]);
+                    if (!PACK) d.bk_w[at] = s_msg[m];
+                    d.bk_inc[at] = s_val[m];
                 }
             }
         }
         __syncthreads();
     }
+    if (BINNED) for (uint32_t i = threadIdx.x; i < bin_cnt; i += BLOCK) bkc[(uint64_t)i * sub] = s_fill[i];
 }
 
 // ---- online walks (query.h:297-300, 320-323; build.h:344-354).  grid = (X, nq).
@@ -1816,7 +1848,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t steps = 0;
     WAVE_STAGE_DECL(st)
-    const bool staged = MODE == WALK_TO_PPR && d.binned && !d.wide;
+    const bool staged = MODE == WALK_TO_PPR && d.binned && !d.wide; // then gridDim.x == d.sub: workgroup x fills sub-bucket x
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * d.sub + blockIdx.x; // count of bin b: bkc[b * sub]
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)MAX_BINS; i += BLOCK) st.fill[i] = i < (uint32_t)d.nbins ? bkc[(uint64_t)i * d.sub] : 0;
+        __syncthreads();
+    }
     for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
@@ -1909,6 +1946,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
         __syncthreads();
     }
     if (staged && st.count) stage_flush(d, q, st);
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += BLOCK) bkc[(uint64_t)i * d.sub] = st.fill[i];
+    }
     const uint64_t ws = wave_sum((uint64_t)steps);
     if ((threadIdx.x & 63) == 0 && ws) atomicAdd(d.tot_steps, (unsigned long long)ws);
 }

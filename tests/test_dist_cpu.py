@@ -64,3 +64,34 @@ def test_shard_layout():
     for r, p in enumerate(parts):
         flat[r * per:r * per + len(p)] = p
     assert flat[unshard_index(10, 4)].tolist() == list(range(10))
+
+
+def _bench(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-only", "--steps", "2", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_gpus_flag_launches_the_ranks():
+    """`bench.py --gpus 2` started plainly launches its two ranks itself (torch.distributed.run, fresh children) and
+    rank 0 reports n_gpus = 2; weak scaling runs --queries per rank, strong scaling shards --queries, and the
+    top-k gather inside the timed region returns the lists in global query order.  --plumbing-only swaps the GPU step
+    for a stand-in and RCCL for gloo; launcher, sharding, barrier / max-over-ranks timing and gather are bench.py's own."""
+    weak = _bench("--gpus", "2", "--queries", "7", "--topk", "4")
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["queries_total_per_step"] == 14
+    assert weak["gather_in_global_order"] is True
+    assert weak["ms_per_step"] >= 20.0  # the slower rank (rank 1 sleeps 20 ms per step) sets the time: max over ranks
+    strong = _bench("--gpus", "2", "--queries", "7", "--topk", "4", "--scaling", "strong")
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["queries_total_per_step"] == 7
+    assert strong["gather_in_global_order"] is True
+    one = _bench("--gpus", "1", "--queries", "5", "--topk", "3")
+    assert one["n_gpus"] == 1 and one["queries_total_per_step"] == 5
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-only", "--gpus", "4"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
