@@ -253,6 +253,7 @@ struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32
 // sub-buckets per (slot, bin) = producer workgroups per slot (Dev::bk_w): ~16 k producer workgroups per launch
 static uint32_t want_sub(const fora_ctx *c, int slots) {
     if (c->opt_.xb > 0) return (uint32_t)std::min<int64_t>(c->opt_.xb, MAX_SUB);
+    if (want_wide(c)) return (uint32_t)std::min(32, std::max(16, 8192 / std::max(1, slots))); // 512-thread producers; LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515, 128 -> 539
     return (uint32_t)std::min(MAX_SUB, std::max(16, 16384 / std::max(1, slots)));
 }
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
@@ -276,7 +277,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
         }
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * 12 + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch;
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -357,7 +358,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
-        HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 4));
+        if (!want_wide(c)) HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 4)); // wide: one 64-bit word per message in bk_inc
         HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * p.sub * 4));
         HIPCHK(c, hipHostMalloc(&c->h_flc, (size_t)FLC_RING * B * 4 * CSTRIDE));
@@ -498,7 +499,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.pass = lo / c->pbins;
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 int h = ev_begin(c, 1);
-                if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
                 else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
@@ -620,7 +621,7 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
-                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BLOCK), 0, c->stream, dp);
+                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
                 hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
             }
     }

@@ -33,7 +33,7 @@ constexpr int MAX_LEVELS = 1 << 15;
 constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
 constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
-constexpr int MAX_BINS_WIDE = 1024; // wide layout (graphs up to 8 M nodes): 12-B push messages (target, increment)
+constexpr int MAX_BINS_WIDE = 1024; // wide layout: up to 1024 bins per pass, 8-byte messages (local target | value << 13)
 #ifndef FORA_ACC_THREADS
 #define FORA_ACC_THREADS 512
 #endif
@@ -44,11 +44,19 @@ constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN
 // slabs in L2 (accumulate kernels -1 %)
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
+#ifndef FORA_BIN_THREADS_WIDE
+#define FORA_BIN_THREADS_WIDE 512
+#endif
+constexpr int BIN_THREADS_WIDE = FORA_BIN_THREADS_WIDE; // wide bin kernel: 512 threads -> 4096-edge chunks, twice the messages per (chunk, bin) run
 constexpr int MAX_SUB = 128; // sub-buckets per (slot, bin) bucket = producer workgroups per slot
 // Narrow layout: a walk result travels as ONE 64-bit word, node id (< 2^20) | weight << 20 (weights are r / num_s_rw,
 // about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
 constexpr int WPACK_SHIFT = 20;
 constexpr uint64_t WPACK_MAXW = 1ull << (64 - WPACK_SHIFT);
+// Wide layout: every message (push increment or walk result) is ONE 64-bit word, local target (BIN_SHIFT bits) | value <<
+// BIN_SHIFT.  A value of 2^51 or more (the increments of the first one or two levels, about 1e-3 and up) goes through the
+// slot's overflow list (push) or a direct atomic (walk weight) and leaves a null word behind.
+constexpr uint64_t WIDE_MAXV = 1ull << (64 - BIN_SHIFT);
 
 // error flag bits (Dev::err)
 constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4, ERR_BUCKET_OVERFLOW = 8;
@@ -264,6 +272,21 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
     }
     total = __shfl(x, 63);
     return x - v;
+}
+// exclusive scan over the NT threads of a block; s_w: NT / 64-entry LDS scratch
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t v, uint32_t *s_w, uint32_t &total) {
+    uint32_t wtot;
+    uint32_t x = wave_excl_scan(v, wtot);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[w] = wtot;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) { const uint32_t c = s_w[i]; if (i < w) before += c; tot += c; }
+    total = tot;
+    return x + before;
 }
 // exclusive scan over the 256 threads of a block; s_w: 4-entry LDS scratch
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t &total) {
@@ -548,7 +571,8 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // consecutive lanes on consecutive edges through an LDS address table, carrying rowinfo in the frontier entry, and
 // loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
 template <int NB>
-__global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
+__global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pushq_bin(Dev d, int L) {
+    constexpr int NT = NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
     const int q = blockIdx.y;
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
@@ -559,15 +583,17 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     }
     if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
-    constexpr uint32_t CHUNK = BLOCK * BIN_EPT;
-    __shared__ int64_t s_ebeg[BLOCK];
-    __shared__ uint64_t s_inc[BLOCK];
-    __shared__ uint32_t s_pref[BLOCK + 1];
-    __shared__ uint32_t s_w[4];
+    constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
+    static_assert(!WIDE || BIN_SHIFT + SRC_BITS + 10 <= 32, "wide stage word: local target | source entry | bin (<= 1024 per pass)");
+    constexpr uint32_t CHUNK = NT * BIN_EPT;
+    __shared__ int64_t s_ebeg[NT];
+    __shared__ uint64_t s_inc[NT];
+    __shared__ uint32_t s_pref[NT + 1];
+    __shared__ uint32_t s_w[NT / 64];
     __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
     __shared__ uint32_t s_fill[NB]; // messages this workgroup has put into its sub-bucket of every bin
     // stage: ONE word per message.  narrow: (local target << SEG_BITS) | frontier position, its bin in s_bin;
-    // wide: local target (13 bits) | source entry inside the tile (8) | bin (10)
+    // wide: local target (13 bits) | source entry inside the tile (SRC_BITS) | bin (10)
     __shared__ uint32_t s_msg[CHUNK];
     __shared__ uint8_t s_bin[WIDE ? 1 : CHUNK]; // narrow: bin of the staged message
     const int lane = threadIdx.x & 63;
@@ -580,13 +606,13 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
     const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap;             // sub-bucket of bin b: bk0 + b * sub * bk_cap
     const uint64_t bstride = (uint64_t)sub * d.bk_cap;
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += NT) {
         s_cnt[i] = 0;
         s_fill[i] = i < bin_cnt ? bkc[(uint64_t)i * sub] : 0;
     }
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
     STAMP_DECL
-    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < count; tbase += gridDim.x * BLOCK) {
+    for (uint32_t tbase = blockIdx.x * NT; tbase < count; tbase += gridDim.x * NT) {
         // ---- one frontier entry per lane
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
@@ -614,9 +640,9 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             cnt = inc ? deg : 0u; // an increment of zero changes nothing: skip the row
         }
         uint32_t total;
-        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        const uint32_t pre = block_excl_scan_n<NT>(cnt, s_w, total);
         s_pref[threadIdx.x] = pre;
-        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        if (threadIdx.x == 0) s_pref[NT] = total;
         __syncthreads();
         STAMP(0);
         // ---- bin the tile's edges
@@ -625,9 +651,9 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             const uint32_t e0 = cb + threadIdx.x * BIN_EPT; // lane t takes 8 consecutive edges: ONE binary search for the source entry
             uint32_t lo = 0;
             if (e0 < total) {
-                uint32_t hi = BLOCK;
+                uint32_t hi = NT;
 #pragma unroll
-                for (int it = 0; it < 8; it++) {
+                for (int it = 0; it < (NT == 256 ? 8 : NT == 512 ? 9 : 10); it++) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (s_pref[mid] <= e0) lo = mid; else hi = mid;
                 }
@@ -654,7 +680,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
             uint32_t staged; // messages of this chunk that belong to the pass's bins
             { // take sub-bucket space (a counter in LDS, no atomic) and lay the bins out in the LDS stage:
               // lane t owns bins t*PER .. t*PER+PER-1
-                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+                constexpr int PER = NB / NT > 0 ? NB / NT : 1;
                 uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
@@ -663,7 +689,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     mine += c[j];
                 }
                 uint32_t ctot;
-                uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
+                uint32_t pre2 = block_excl_scan_n<NT>(mine, s_w, ctot);
                 staged = ctot;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
@@ -688,23 +714,28 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
                     const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
                     const uint32_t own = si[k];
-                    if (WIDE) s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) | (b << (BIN_SHIFT + 8));
+                    if (WIDE) s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) | (b << (BIN_SHIFT + SRC_BITS));
                     else { s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own); s_bin[sp] = (uint8_t)b; }
                 }
             }
             __syncthreads();
             STAMP(3);
-            for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) { // consecutive lanes -> consecutive bucket slots
+            for (uint32_t m = threadIdx.x; m < staged; m += NT) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t e = s_msg[m];
                 uint32_t b, sidx, local;
-                if (WIDE) { b = e >> (BIN_SHIFT + 8); sidx = (e >> BIN_SHIFT) & 255u; local = e & (BIN_SIZE - 1); }
+                if (WIDE) { b = e >> (BIN_SHIFT + SRC_BITS); sidx = (e >> BIN_SHIFT) & (uint32_t)(NT - 1); local = e & (BIN_SIZE - 1); }
                 else { b = s_bin[m]; sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
                 const uint32_t pos = s_base[b] + (m - s_lofs[b]);
-                if (pos < d.bk_cap) {
-                    const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
-                    if (WIDE) { d.bk_w[at] = local; d.bk_inc[at] = s_inc[sidx]; }
-                    else d.bk_w[at] = e;
-                } else { // bucket full: park the increment in the slot's overflow list
+                const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
+                bool parked = pos >= d.bk_cap; // sub-bucket full
+                if (!parked) {
+                    if (WIDE) {
+                        const uint64_t inc = s_inc[sidx];
+                        parked = inc >= WIDE_MAXV; // does not fit the packed word: null word here, the increment goes to the list
+                        d.bk_inc[at] = parked ? 0ull : (uint64_t)local | (inc << BIN_SHIFT);
+                    } else d.bk_w[at] = e;
+                }
+                if (parked) { // park the increment in the slot's overflow list, folded in by k_accum
                     const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
                     if (oi < d.ov_cap) {
                         d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
@@ -717,7 +748,7 @@ __global__ void __launch_bounds__(BLOCK) k_pushq_bin(Dev d, int L) {
         __syncthreads();
         STAMP(5);
     }
-    for (uint32_t i = threadIdx.x; i < bin_cnt; i += BLOCK) bkc[(uint64_t)i * sub] = s_fill[i];
+    for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
     STAMP_FLUSH(0);
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
@@ -872,7 +903,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint64_t acc[BIN_SIZE];
     constexpr int NW = ACC_THREADS / 64;
     constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
-    __shared__ uint32_t s_rank[TO_PPR ? 1 : SWEEP * NW + 1];
+    __shared__ uint32_t s_rank[SWEEP * NW + 1];
     __shared__ uint32_t s_gbase;
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
     __shared__ uint32_t s_nlist;
@@ -912,8 +943,12 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     const uint64_t bk0 = bi * sub * d.bk_cap; // sub-bucket x starts at bk0 + x * bk_cap
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
     const uint64_t *itab = TO_PPR ? nullptr : d.inc_tab[par] + (uint64_t)q * d.segq_cap;
+    // message forms: narrow push = 4-byte word (local target << SEG_BITS | frontier position), increment gathered from the
+    // table; everything else = ONE 64-bit word in bk_inc: narrow walk results node id | weight << WPACK_SHIFT, wide
+    // messages local target | value << BIN_SHIFT
     const bool gather = !TO_PPR && !d.wide;
-    const bool packed = TO_PPR && !d.wide; // narrow walk results: node id | weight << WPACK_SHIFT in bk_inc only
+    const bool packed = !gather;
+    const int pshift = d.wide ? BIN_SHIFT : WPACK_SHIFT;
     if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
         // node range and the level's pops are done, so nothing else touches these words).  Wave w takes sub-buckets
@@ -927,15 +962,13 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 uint32_t w = 0;
                 uint64_t inc = 0;
                 if (i < n_x && x < sub) {
-                    if (packed) { // narrow walk results: one packed word, node id | weight << WPACK_SHIFT
+                    if (packed) {
                         const uint64_t pk = d.bk_inc[at0 + i];
-                        w = (uint32_t)pk & ((1u << WPACK_SHIFT) - 1);
-                        inc = pk >> WPACK_SHIFT;
-                    } else w = d.bk_w[at0 + i];
-                    if (TO_PPR && d.wide) inc = d.bk_inc[at0 + i];
-                    else if (TO_PPR) {}
-                    else if (d.wide) { inc = d.bk_inc[at0 + i]; w = node0 + w; }
-                    else {
+                        w = (uint32_t)pk & ((1u << pshift) - 1);
+                        if (d.wide) w += node0;
+                        inc = pk >> pshift;
+                    } else {
+                        w = d.bk_w[at0 + i];
                         inc = itab[w & ((1u << SEG_BITS) - 1)];
                         w = node0 + (w >> SEG_BITS);
                     }
@@ -979,7 +1012,9 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     STAMP(16);
     // messages: wave w takes sub-buckets w, w + NW, ...; ACC_UNROLL x 64 messages per iteration, all loads BRANCH-FREE
     // (clamped index, masked afterwards).  With an `if (i < cnt)` around each load hipcc puts every dependent increment
-    // gather behind its own s_waitcnt vmcnt(0): serialized round trips instead of two per iteration.
+    // gather behind its own s_waitcnt vmcnt(0): serialized round trips instead of two per iteration.  (Cutting the
+    // sub-buckets into 64-message units dealt round-robin to the waves -- no idle lanes but a 7-step search per unit --
+    // was measured: accumulate 43 -> 59 ms per 1000 ws queries.)
     constexpr int ACC_UNROLL = 4;
     for (uint32_t x = wid; x < sub; x += NW) {
         const uint32_t n_x = s_scnt[x];
@@ -1000,9 +1035,9 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
-                uint32_t local = gather ? mw[k] >> SEG_BITS : mw[k];
+                uint32_t local = mw[k] >> SEG_BITS;
                 uint64_t inc = mi[k];
-                if (packed) { local = (uint32_t)inc; inc >>= WPACK_SHIFT; }
+                if (packed) { local = (uint32_t)inc; inc >>= pshift; }
                 if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
             }
         }
@@ -1682,16 +1717,22 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
 // go through the same block-level chunk binning as the push (LDS histogram, one global atomic per
 // (chunk, bin), bin-sorted LDS stage, run write-out) and are reduced by k_accum<true>.
 template <int NB>
-__global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
+__global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_walk_idx(Dev d) {
+    constexpr int NT = NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK; // workgroup size = walk items per tile
     constexpr int EPT = BIN_EPT;
-    __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
-    __shared__ uint32_t s_pref[BLOCK + 1], s_w[4];
-    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    __shared__ uint32_t s_fill[NB]; // messages this workgroup has put into its sub-bucket of every bin (see Dev::bk_w)
+    constexpr uint32_t CHUNK = NT * EPT;
     constexpr bool BINNED = NB > 1;
-    constexpr bool PACK = BINNED && NB <= MAX_BINS; // narrow: one word per result, node id | weight << WPACK_SHIFT
-    __shared__ uint32_t s_msg[BINNED && !PACK ? BLOCK * EPT : 1], s_dst[NB > 1 ? BLOCK * EPT : 1];
-    __shared__ uint64_t s_val[NB > 1 ? BLOCK * EPT : 1];
+    constexpr bool WIDE = NB > MAX_BINS;
+    constexpr int IB = NT == 256 ? 8 : NT == 512 ? 9 : 10; // bits of an item index inside the tile
+    constexpr int DB = WIDE ? BIN_SHIFT : WPACK_SHIFT;     // bits of the destination in a stage word: local target / node id
+    static_assert(DB + IB + 1 <= 32, "stage word: destination | item | carries-one-more-unit");
+    __shared__ uint64_t s_j0[NT], s_pos[NT], s_incr[NT], s_rem[NT];
+    __shared__ uint32_t s_pref[NT + 1], s_w[NT / 64];
+    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_fill[NB]; // results this workgroup has put into its sub-bucket of every bin (see Dev::bk_w)
+    // stage: ONE word per result (destination | item << DB | extra unit << (DB + IB)) and its bin; the weight comes from the item
+    __shared__ uint32_t s_msg[BINNED ? CHUNK : 1];
+    __shared__ uint16_t s_bin[BINNED ? CHUNK : 1];
     const int q = blockIdx.y;
     const uint32_t nitems = d.wit_count[q * CSTRIDE];
     if (!nitems) return;
@@ -1701,11 +1742,11 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + blockIdx.x;      // count of bin b: bkc[b * sub]
     const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap; // sub-bucket of bin b: bk0 + b * sub * bk_cap
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
-    if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += BLOCK) {
+    if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += NT) {
         s_cnt[i] = 0;
         s_fill[i] = i < bin_cnt ? bkc[(uint64_t)i * sub] : 0;
     }
-    for (uint32_t tbase = blockIdx.x * BLOCK; tbase < nitems; tbase += gridDim.x * BLOCK) {
+    for (uint32_t tbase = blockIdx.x * NT; tbase < nitems; tbase += gridDim.x * NT) {
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
         if (i < nitems) {
@@ -1715,24 +1756,22 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
             cnt = w.idx_n;
         }
         uint32_t total;
-        const uint32_t pre = block_excl_scan(cnt, s_w, total);
+        const uint32_t pre = block_excl_scan_n<NT>(cnt, s_w, total);
         s_pref[threadIdx.x] = pre;
-        if (threadIdx.x == 0) s_pref[BLOCK] = total;
+        if (threadIdx.x == 0) s_pref[NT] = total;
         __syncthreads();
-        for (uint32_t cb = 0; cb < total; cb += BLOCK * EPT) {
-            uint32_t dest[EPT], rank[EPT];
-            uint64_t wgt[EPT];
+        for (uint32_t cb = 0; cb < total; cb += CHUNK) {
+            uint32_t dest[EPT], rank[EPT], li[EPT];
             const uint32_t e0 = cb + threadIdx.x * EPT;
             uint32_t lo = 0;
             if (e0 < total) {
-                uint32_t hi = BLOCK;
+                uint32_t hi = NT;
 #pragma unroll
-                for (int it = 0; it < 8; it++) {
+                for (int it = 0; it < IB; it++) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (s_pref[mid] <= e0) lo = mid; else hi = mid;
                 }
             }
-            uint32_t li[EPT];
 #pragma unroll
             for (int k = 0; k < EPT; k++) { // items can be empty here (idx_n == 0): advance past them
                 const uint32_t e = e0 + k;
@@ -1743,28 +1782,19 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
             for (int k = 0; k < EPT; k++) { // straight-line: all EPT gathers in flight together
                 const uint32_t e = e0 + k;
                 dest[k] = 0xFFFFFFFFu;
-                wgt[k] = 0;
                 if (e < total) {
                     const uint32_t jj = e - s_pref[li[k]];
-                    const uint64_t j = s_j0[li[k]] + jj;
-                    dest[k] = (uint32_t)d.rw_idx[s_pos[li[k]] + jj];    // query.h:292
-                    wgt[k] = s_incr[li[k]] + (j < s_rem[li[k]] ? 1 : 0); // query.h:293
+                    dest[k] = (uint32_t)d.rw_idx[s_pos[li[k]] + jj];                       // query.h:292
+                    li[k] |= (s_j0[li[k]] + jj < s_rem[li[k]] ? 1u : 0u) << IB;              // query.h:293: the first `rem` walks carry one more unit
                 }
             }
             if (!BINNED) {
 #pragma unroll
                 for (int k = 0; k < EPT; k++)
                     if (dest[k] != 0xFFFFFFFFu)
-                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
+                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]],
+                                  (unsigned long long)(s_incr[li[k] & (NT - 1)] + (li[k] >> IB)));
                 continue;
-            }
-            if (PACK) {
-#pragma unroll
-                for (int k = 0; k < EPT; k++)
-                    if (dest[k] != 0xFFFFFFFFu && wgt[k] >= WPACK_MAXW) { // does not fit the packed word
-                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
-                        dest[k] = 0xFFFFFFFFu;
-                    }
             }
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
@@ -1774,7 +1804,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
             __syncthreads();
             uint32_t staged; // results of this chunk that belong to the pass's bins
             {
-                constexpr int PER = NB / BLOCK > 0 ? NB / BLOCK : 1;
+                constexpr int PER = NB / NT > 0 ? NB / NT : 1;
                 uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
@@ -1783,7 +1813,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
                     mine += c[j];
                 }
                 uint32_t ctot;
-                uint32_t pre2 = block_excl_scan(mine, s_w, ctot);
+                uint32_t pre2 = block_excl_scan_n<NT>(mine, s_w, ctot);
                 staged = ctot;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
@@ -1805,28 +1835,26 @@ __global__ void __launch_bounds__(BLOCK) k_walk_idx(Dev d) {
             for (int k = 0; k < EPT; k++) {
                 if (dest[k] != 0xFFFFFFFFu) {
                     const uint32_t b = (dest[k] >> BIN_SHIFT) - bin_lo;
-                    const uint32_t pos = s_base[b] + rank[k];
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    if (PACK) s_val[sp] = (uint64_t)dest[k] | (wgt[k] << WPACK_SHIFT);
-                    else { s_msg[sp] = dest[k]; s_val[sp] = wgt[k]; }
-                    s_dst[sp] = pos < d.bk_cap ? b : 0xFFFFFFFFu; // bin; the slot inside the sub-bucket follows from the stage position
-                    if (pos >= d.bk_cap) // bucket full: direct atomic, same sum
-                        atomicAdd((unsigned long long *)&d.ppr[slab + dest[k]], (unsigned long long)wgt[k]);
+                    s_msg[sp] = (WIDE ? dest[k] & (BIN_SIZE - 1) : dest[k]) | (li[k] << DB);
+                    s_bin[sp] = (uint16_t)b;
                 }
             }
             __syncthreads();
-            for (uint32_t m = threadIdx.x; m < staged; m += BLOCK) {
-                const uint32_t bb = s_dst[m];
-                if (bb != 0xFFFFFFFFu) {
-                    const uint64_t at = bk0 + (uint64_t)bb * sub * d.bk_cap + s_base[bb] + (m - s_lofs[bb]);
-                    if (!PACK) d.bk_w[at] = s_msg[m];
-                    d.bk_inc[at] = s_val[m];
-                }
+            for (uint32_t m = threadIdx.x; m < staged; m += NT) { // consecutive lanes -> consecutive sub-bucket slots
+                const uint32_t e = s_msg[m], b = s_bin[m];
+                const uint32_t dd = e & ((1u << DB) - 1);
+                const uint64_t wgt = s_incr[(e >> DB) & (uint32_t)(NT - 1)] + (e >> (DB + IB));
+                const uint32_t pos = s_base[b] + (m - s_lofs[b]);
+                const bool fits = wgt < (WIDE ? WIDE_MAXV : WPACK_MAXW);
+                if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * sub * d.bk_cap + pos] = fits ? (uint64_t)dd | (wgt << DB) : 0ull;
+                if (pos >= d.bk_cap || !fits) // sub-bucket full / weight too large for the packed word: direct atomic, same sum
+                    atomicAdd((unsigned long long *)&d.ppr[slab + (WIDE ? ((bin_lo + b) << BIN_SHIFT) | dd : dd)], (unsigned long long)wgt);
             }
         }
         __syncthreads();
     }
-    if (BINNED) for (uint32_t i = threadIdx.x; i < bin_cnt; i += BLOCK) bkc[(uint64_t)i * sub] = s_fill[i];
+    if (BINNED) for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
 }
 
 // ---- online walks (query.h:297-300, 320-323; build.h:344-354).  grid = (X, nq).
