@@ -352,7 +352,7 @@ def main():
         if not args.no_cpu:
             import oracle_lib as O
             g = O.Graph(n, m, row_ptr, col)
-            per_query_guess = 0.35e-6 * m  # one FIFO push is a few sweeps of the edge list on one core
+            per_query_guess = 0.05e-6 * m  # one oracle query: LJ-sized 3.4 s, Twitter-sized about 75 s of one core
             if world == 1 and per_query_guess <= args.cpu_seconds:  # the CPU baseline is timed at N = 1 only
                 index = None
                 if args.with_idx:

@@ -231,8 +231,14 @@ constexpr int FLC_RING = SPEC + 2;
 
 static bool want_binned(const fora_ctx *c) { return c->opt_.direct != 1; } // direct: the one-atomic-per-edge path (tests)
 // bins handled per pass in the wide layout (graphs with more bins run several bin/accum passes per level)
-static int want_pass_bins(const fora_ctx *c) {
-    return c->opt_.pass_bins > 0 ? (int)std::min<int64_t>(c->opt_.pass_bins, MAX_BINS_WIDE) : (int)MAX_BINS_WIDE;
+static int want_pass_bins(const fora_ctx *c, int nbins) {
+    // graphs with more than 1024 bins run several passes per level; up to 2560 bins per pass then (the per-pass
+    // re-scan of the frontier and of the walk index costs more than the shorter message runs: Twitter-2010-sized,
+    // 26 queries, bins per pass 256 / 512 / 1024: 7.5 / 4.3 / 3.0 s)
+    const int cap = nbins > MAX_BINS_WIDE ? MAX_BINS_HUGE : MAX_BINS_WIDE;
+    if (c->opt_.pass_bins > 0 && c->opt_.pass_bins != MAX_BINS_WIDE) return (int)std::min<int64_t>(c->opt_.pass_bins, cap);
+    if (nbins > cap) { const int np = (nbins + cap - 1) / cap; return (nbins + np - 1) / np; } // equal passes
+    return cap;
 }
 // narrow layout: <= MAX_BINS bins and the slice index fits the 4-byte push message
 static bool want_wide(const fora_ctx *c) {
@@ -253,7 +259,7 @@ struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32
 // sub-buckets per (slot, bin) = producer workgroups per slot (Dev::bk_w): ~16 k producer workgroups per launch
 static uint32_t want_sub(const fora_ctx *c, int slots) {
     if (c->opt_.xb > 0) return (uint32_t)std::min<int64_t>(c->opt_.xb, MAX_SUB);
-    if (want_wide(c)) return (uint32_t)std::min(32, std::max(16, 8192 / std::max(1, slots))); // 512-thread producers; LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515, 128 -> 539
+    if (want_wide(c)) return slots >= 32 ? 32u : 64u; // 512-thread producers, 2 resident per CU; LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515, 128 -> 539
     return (uint32_t)std::min(MAX_SUB, std::max(16, 16384 / std::max(1, slots)));
 }
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
@@ -266,7 +272,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
         p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
-        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c)) : p.nbins;
+        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c, p.nbins)) : p.nbins;
         p.sub = want_sub(c, slots);
         { // capacity of one sub-bucket: the bucket's capacity over its sub-buckets (+25 % for uneven producers); the
           // `bkcap` option (tests) sets it directly
@@ -499,7 +505,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.pass = lo / c->pbins;
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 int h = ev_begin(c, 1);
-                if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
+                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
+                else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
                 else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
@@ -621,7 +628,8 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
-                hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
+                if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
+                else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
                 hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
             }
     }

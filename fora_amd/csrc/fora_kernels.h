@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fora {
 
@@ -33,7 +34,8 @@ constexpr int MAX_LEVELS = 1 << 15;
 constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
 constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
-constexpr int MAX_BINS_WIDE = 1024; // wide layout: up to 1024 bins per pass, 8-byte messages (local target | value << 13)
+constexpr int MAX_BINS_WIDE = 1024; // wide layout: 8-byte messages (local target | value << 13), up to 1024 bins per pass ...
+constexpr int MAX_BINS_HUGE = 2560; // ... or 2560 for graphs with more bins (Twitter-2010: 5085 bins in 2 passes instead of 5)
 #ifndef FORA_ACC_THREADS
 #define FORA_ACC_THREADS 512
 #endif
@@ -584,18 +586,20 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
     if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
-    static_assert(!WIDE || BIN_SHIFT + SRC_BITS + 10 <= 32, "wide stage word: local target | source entry | bin (<= 1024 per pass)");
+    static_assert(BIN_SHIFT + SRC_BITS <= 32, "wide stage word: local target | source entry");
     constexpr uint32_t CHUNK = NT * BIN_EPT;
     __shared__ int64_t s_ebeg[NT];
     __shared__ uint64_t s_inc[NT];
     __shared__ uint32_t s_pref[NT + 1];
     __shared__ uint32_t s_w[NT / 64];
-    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
-    __shared__ uint32_t s_fill[NB]; // messages this workgroup has put into its sub-bucket of every bin
-    // stage: ONE word per message.  narrow: (local target << SEG_BITS) | frontier position, its bin in s_bin;
-    // wide: local target (13 bits) | source entry inside the tile (SRC_BITS) | bin (10)
+    // per bin: messages of the chunk, first stage slot of the bin (s_lofs[b + 1] - s_lofs[b] = that count again), and
+    // s_fill: messages this workgroup has put into its sub-bucket of the bin so far
+    __shared__ uint32_t s_cnt[NB], s_lofs[NB + 1];
+    __shared__ uint32_t s_fill[NB];
+    // stage: ONE word per message and its bin.  narrow: (local target << SEG_BITS) | frontier position;
+    // wide: local target (13 bits) | source entry inside the tile (SRC_BITS)
     __shared__ uint32_t s_msg[CHUNK];
-    __shared__ uint8_t s_bin[WIDE ? 1 : CHUNK]; // narrow: bin of the staged message
+    __shared__ typename std::conditional<WIDE, uint16_t, uint8_t>::type s_bin[CHUNK];
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint64_t fbase = (uint64_t)q * d.segq_cap;
@@ -698,13 +702,12 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) {
-                            const uint32_t f = s_fill[b];
-                            s_base[b] = f;
-                            s_fill[b] = f + c[j];
+                            s_fill[b] += c[j];
                             s_cnt[b] = 0;
                         }
                     }
                 }
+                if (threadIdx.x == NT - 1) s_lofs[NB] = ctot;
             }
             __syncthreads();
             STAMP(2);
@@ -714,18 +717,19 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
                     const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
                     const uint32_t own = si[k];
-                    if (WIDE) s_msg[sp] = (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) | (b << (BIN_SHIFT + SRC_BITS));
-                    else { s_msg[sp] = ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own); s_bin[sp] = (uint8_t)b; }
+                    s_msg[sp] = WIDE ? (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) : ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own);
+                    s_bin[sp] = b;
                 }
             }
             __syncthreads();
             STAMP(3);
             for (uint32_t m = threadIdx.x; m < staged; m += NT) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t e = s_msg[m];
-                uint32_t b, sidx, local;
-                if (WIDE) { b = e >> (BIN_SHIFT + SRC_BITS); sidx = (e >> BIN_SHIFT) & (uint32_t)(NT - 1); local = e & (BIN_SIZE - 1); }
-                else { b = s_bin[m]; sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
-                const uint32_t pos = s_base[b] + (m - s_lofs[b]);
+                const uint32_t b = s_bin[m];
+                uint32_t sidx, local;
+                if (WIDE) { sidx = e >> BIN_SHIFT; local = e & (BIN_SIZE - 1); }
+                else { sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
+                const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk: its messages end at s_fill[b]
                 const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
                 bool parked = pos >= d.bk_cap; // sub-bucket full
                 if (!parked) {
@@ -1728,7 +1732,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_wa
     static_assert(DB + IB + 1 <= 32, "stage word: destination | item | carries-one-more-unit");
     __shared__ uint64_t s_j0[NT], s_pos[NT], s_incr[NT], s_rem[NT];
     __shared__ uint32_t s_pref[NT + 1], s_w[NT / 64];
-    __shared__ uint32_t s_cnt[NB], s_base[NB], s_lofs[NB];
+    __shared__ uint32_t s_cnt[NB], s_lofs[NB + 1];
     __shared__ uint32_t s_fill[NB]; // results this workgroup has put into its sub-bucket of every bin (see Dev::bk_w)
     // stage: ONE word per result (destination | item << DB | extra unit << (DB + IB)) and its bin; the weight comes from the item
     __shared__ uint32_t s_msg[BINNED ? CHUNK : 1];
@@ -1822,13 +1826,12 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_wa
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) { // space in the workgroup's own sub-bucket: a counter in LDS, no global atomic
-                            const uint32_t f = s_fill[b];
-                            s_base[b] = f;
-                            s_fill[b] = f + c[j];
+                            s_fill[b] += c[j];
                             s_cnt[b] = 0;
                         }
                     }
                 }
+                if (threadIdx.x == NT - 1) s_lofs[NB] = ctot;
             }
             __syncthreads();
 #pragma unroll
@@ -1845,7 +1848,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_wa
                 const uint32_t e = s_msg[m], b = s_bin[m];
                 const uint32_t dd = e & ((1u << DB) - 1);
                 const uint64_t wgt = s_incr[(e >> DB) & (uint32_t)(NT - 1)] + (e >> (DB + IB));
-                const uint32_t pos = s_base[b] + (m - s_lofs[b]);
+                const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk
                 const bool fits = wgt < (WIDE ? WIDE_MAXV : WPACK_MAXW);
                 if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * sub * d.bk_cap + pos] = fits ? (uint64_t)dd | (wgt << DB) : 0ull;
                 if (pos >= d.bk_cap || !fits) // sub-bucket full / weight too large for the packed word: direct atomic, same sum
