@@ -66,6 +66,17 @@ def build_tools(force=False):
     return lib
 
 
+def build_c_smoke(force=False):
+    """The reference-side binding of INTEGRATION.md as a plain C program (gcc, -lfora_hip)."""
+    src = os.path.join(ROOT, "tests", "c_smoke", "integration_smoke.c")
+    exe = os.path.join(ROOT, "tests", "c_smoke", "integration_smoke")
+    if not force and _newer(exe, [src, LIB, os.path.join(ROOT, "include", "fora_hip.h")]):
+        return exe
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
+                    "-L", PKG, "-lfora_hip", "-lm", "-Wl,-rpath,$ORIGIN/../../fora_amd", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
 def build_oracle():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     return os.path.join(ROOT, "oracle", "libfora_oracle.so")
@@ -75,6 +86,7 @@ def build_all(force=False):
     build_hip(force)
     build_cli(force)
     build_tools(force)
+    build_c_smoke(force)
     build_oracle()
 
 

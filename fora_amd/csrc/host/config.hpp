@@ -55,6 +55,7 @@ struct Config { // config.h:86-160
     int device = 0;
     int batch = 0;
     bool boost_idx = false;    // build --boost_idx: write the index as Boost binary archives (presumed 1.65 layout)
+    bool oversubscribe = false; // --gpus N larger than the device count: several contexts per device (tests of the sharded driver)
     double balanced_start = 0; // --balanced_start S: first rmax of --balanced = S * rmax (0: the reference's 8)
     int gpus = 1;   // --gpus N: sources i mod N on GPU (device + i mod N), one host thread per GPU
     std::string get_graph_folder() const { return prefix + graph_alias + "/"; } // config.h:99-101

@@ -204,6 +204,10 @@ static int run_sharded(const Graph &graph, const std::vector<int32_t> &queries, 
                        const IndexData *index, std::vector<Shard> &shards, Work work) {
     int ndev = fora_hip_device_count();
     if (ndev <= 0) { cerr << "no usable MI355X (gfx950) device" << endl; return 1; }
+    if (config.gpus > ndev && !config.oversubscribe) { // two contexts on one GPU would each size their batch from 40 % of its HBM
+        cerr << "--gpus " << config.gpus << " but only " << ndev << " device(s) visible; using " << ndev << endl;
+        config.gpus = ndev;
+    }
     const int G = std::max(1, config.gpus);
     shards.assign((size_t)G, Shard());
     for (unsigned i = 0; i < query_size; i++) {
@@ -391,7 +395,7 @@ static int do_batch_topk(Graph &graph) { // batch_topk(), query.h:1517-1640, FOR
     }
     std::vector<unsigned> ks; // :1585-1591
     const unsigned step = config.k / 5;
-    if (step > 0) for (unsigned i = 1; i < 5; i++) ks.push_back(i * step);
+    if (step > 0) for (unsigned i = 1; i < 5; i++) if (i * step >= 2) ks.push_back(i * step); // get_topk needs k > 1
     ks.push_back(config.k);
     struct Pred { double precision = 0, recall = 0; int count = 0; };
     std::map<unsigned, Pred> pred;
@@ -420,9 +424,9 @@ static int do_batch_topk(Graph &graph) { // batch_topk(), query.h:1517-1640, FOR
     cout << config.algo << endl;
     for (unsigned k : ks) cout << k << "\t";
     cout << endl << "Precision:" << endl;
-    for (unsigned k : ks) cout << pred[k].precision / pred[k].count << "\t";
+    for (unsigned k : ks) cout << (pred[k].count ? pred[k].precision / pred[k].count : 0.0) << "\t";
     cout << endl << "Recall:" << endl;
-    for (unsigned k : ks) cout << pred[k].recall / pred[k].count << "\t";
+    for (unsigned k : ks) cout << (pred[k].count ? pred[k].recall / pred[k].count : 0.0) << "\t";
     cout << endl;
     return 0;
 }
@@ -497,6 +501,9 @@ static int do_build(Graph &graph) { // build(), build.h:302-366
     rw.resize(total);
     info("rw_idx.size()", rw.size());
     string err;
+    if (config.boost_idx)
+        cerr << "warning: --boost_idx writes the layout Boost's binary_oarchive is documented to produce; no reference-written "
+                "file was available to check it against (experimental, see INTEGRATION.md 7)" << endl;
     const bool wrote = config.boost_idx ? IndexFile::write_boost(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err)
                                         : IndexFile::write(config.graph_location, config.rmax_scale, config.opt, graph.n, rw, off, cnt, err);
     if (!wrote) {
@@ -541,6 +548,7 @@ int main(int argc, char *argv[]) {
         else if (arg == "--opt") config.opt = true;
         else if (arg == "--balanced") config.balanced = true;
         else if (arg == "--boost_idx") config.boost_idx = true;
+        else if (arg == "--oversubscribe") config.oversubscribe = true; // tests: --gpus N contexts on fewer devices
         else if (arg == "--balanced_start") config.balanced_start = atof(next("--balanced_start"));
         else if (arg == "--seed") config.seed = strtoull(next("--seed"), nullptr, 0);
         else if (arg == "--device") config.device = atoi(next("--device"));

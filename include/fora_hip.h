@@ -9,9 +9,27 @@
  * ctx is used by one host thread at a time.  All host pointers are ordinary
  * pageable memory; the library copies.
  *
- * Arithmetic: residue / reserve / ppr are kept on the device as unsigned 2^-62
- * fixed point (1.0 == FORA_FIX_ONE) so that every accumulation is an exact,
- * order-independent integer atomic; double-typed outputs are value * 2^-62.
+ * NUMERIC CONTRACT.  residue / reserve / ppr live on the device as unsigned 2^-62 fixed point
+ * (1.0 == FORA_FIX_ONE), so every accumulation is an exact, order-independent integer add:
+ *   - results are bit-reproducible (same inputs, same seed -> same bits, whatever the batch size, the bucket
+ *     layout or the GPU count) and equal oracle/fora_twin.c bit for bit;
+ *   - mass is conserved EXACTLY: after the push sum(reserve) + sum(residue) == FORA_FIX_ONE, after the refinement
+ *     sum(ppr) == FORA_FIX_ONE (fora_query_stats.ppr_sum_fix); walk j of a residue node carries floor(r / num_s_rw)
+ *     plus one more unit for j < r mod num_s_rw;
+ *   - a pop keeps floor(alpha * r) -- alpha enters as floor(alpha * 2^62) -- and every out-edge gets
+ *     floor((r - keep) / outdeg); the division remainder (< outdeg units of 2^-62 = 2.2e-19) stays in the RESERVE of
+ *     the popped node, where the reference's f64 `((1-alpha)*r)/outdeg` (algo.h:1002) rounds instead;
+ *   - the threshold test residue/outdeg >= rmax (algo.h:1012) is residue >= ceil(rmax * 2^62) * outdeg;
+ *   - double-typed outputs (ppr_out, scores, rsum) are value * 2^-62: absolute resolution 2.2e-19, i.e. at least
+ *     9 significant digits for any entry >= 1/n of a graph of up to 2^31 nodes.
+ * ERROR BOUND of ppr_out against exact PPR pi(s, .) (power iteration, query.h:1192-1224): the FORA guarantee the
+ * parameters of algo.h:455-463 encode, |ppr - pi| <= epsilon * pi for every pi >= 1/n with probability
+ * 1 - 1/n; the fixed point adds at most (pops + relaxations + walks) * 2^-62 < 1e-8 * that bound.  Checked at
+ * n = 281 904 in tests/test_hip_parity_gpu.py::test_full_size_webstanford_properties (L-inf <= 2e-5).
+ * RNG CONTRACT, version 2 (replaces the time(0)-seeded Boost engines of algo.h:105-122): Philox4x32-10, key = seed,
+ * one call per two steps, counter = (start node, walk# lo32, walk# bits 32..47 | round << 16 | (step/2 & 255) << 24,
+ * stream ^ (step >> 9) * 0x9E3779B9), stream = the query's source id (FORA_STREAM_INDEX for index walks).
+ * Version 1 (round 1) lacked the (step >> 9) term; walks of up to 512 steps are identical in both.
  */
 #ifndef FORA_HIP_H
 #define FORA_HIP_H

@@ -47,3 +47,15 @@ def test_no_gpu_no_fallback():
     import fora_amd
     with pytest.raises(fora_amd.ForaError):
         fora_amd.Engine(0)
+
+
+def test_c_binding_compiles_and_fails_loudly_without_gpu():
+    """tests/c_smoke/integration_smoke.c is INTEGRATION.md's reference-side binding as a plain C program (gcc -std=c99,
+    -lfora_hip).  Here (no GPU) it must build, link and stop at fora_hip_create with FORA_E_NOGPU -- exit code 77."""
+    import subprocess
+    from fora_amd import build
+    exe = build.build_c_smoke(force=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 77, (r.returncode, r.stderr)

@@ -148,11 +148,11 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
     assert [int(x.split(":")[0]) for x in got[1:]] == ids.tolist()
     assert [float(x.split(":")[1]) for x in got[1:]] == sc.tolist()
     # --gpus 2: two host threads / contexts (both land on this box's single GPU), sources i mod 2, same results
-    r2 = _run([cli, "topk", "--algo", "fora", "--opt", "--with_idx", "--k", "20", "--query_size", "5", "--gpus", "2",
+    r2 = _run([cli, "topk", "--algo", "fora", "--opt", "--with_idx", "--k", "20", "--query_size", "5", "--gpus", "2", "--oversubscribe",
                "--result_dir", str(tmp_path / "res2"), *common[:6]])
     assert r2.returncode == 0, r2.stderr
     assert open(tmp_path / "res2" / "g32k.topk.k-20.txt").read() == open(tmp_path / "res" / "g32k.topk.k-20.txt").read()
-    r2 = _run([cli, "query", "--algo", "fora", "--query_size", "10", "--gpus", "3", "--result_dir", str(tmp_path / "res2"), *common[:6]])
+    r2 = _run([cli, "query", "--algo", "fora", "--query_size", "10", "--gpus", "3", "--oversubscribe", "--result_dir", str(tmp_path / "res2"), *common[:6]])
     assert r2.returncode == 0, r2.stderr
     j2 = json.load(open(tmp_path / "res2" / "execution" / "g32k.query.fora.without_idx.k-500.rmax-1.000000.json"))
     j1 = json.load(open(tmp_path / "res" / "execution" / "g32k.query.fora.without_idx.k-500.rmax-1.000000.json"))

@@ -106,3 +106,14 @@ def test_bucket_overflow_is_retried_with_larger_buckets(engine, oracle, small, m
     assert rounds[0] == wr and (ids[0] == wid).all() and (sc[0] == wsc).all()
     engine.reset_options()
     engine.set_graph(g.n, g.m, g.row_ptr, g.col)   # a new graph starts from the default capacity again
+
+
+def test_c_binding_runs_end_to_end():
+    """INTEGRATION.md's call sequence, compiled as C and linked against libfora_hip.so, on the GPU."""
+    import os
+    import subprocess
+    from fora_amd import build
+    exe = build.build_c_smoke()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c smoke ok" in r.stdout

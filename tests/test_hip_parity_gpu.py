@@ -155,8 +155,8 @@ def test_vs_reference_order_oracle_and_exact_ppr(engine, oracle, small, opt):
         assert np.abs(ppr[i] - ref).max() <= 1e-3
         big = exact >= 1.0 / g.n
         assert (np.abs(ppr[i] - exact)[big] / exact[big]).max() <= eps
-        # reserve side: push states differ by schedule only
-        assert abs(st[i]["rsum"] - rst["rsum"]) < 0.05
+        # reserve side: push states differ by schedule only; either push stops with every residue under rmax * outdeg
+        assert 0 <= st[i]["rsum"] < g.col.size * rmax and 0 <= rst["rsum"] < g.col.size * rmax
 
 
 def test_batching_and_determinism(engine, oracle, small):
@@ -194,8 +194,10 @@ def test_error_behaviour(engine, oracle, tiny):
 
 
 def test_full_size_webstanford_properties(engine, oracle):
-    """BASELINE size (n=281 904, m=2 312 497): properties that need no oracle run --
-    exact mass conservation per query, exit condition of the push, determinism."""
+    """BASELINE size (n=281 904, m=2 312 497), online walks and --with_idx: exact mass conservation per query, the
+    push's exit condition over ALL nodes, determinism, one query bit for bit against the twin -- and the float side
+    of the bar at this size: four sources against the reference-order f64 oracle (FIFO push, query.h:841-907) and
+    against exact PPR (CPU power iteration, query.h:1192-1224), with the tolerances stated here."""
     from fora_amd import synth
     n, m, row_ptr, col = synth.preset("webstanford")
     engine.clear_index()
@@ -206,11 +208,13 @@ def test_full_size_webstanford_properties(engine, oracle):
     srcs = synth.query_set(n, 64, 7)
     ppr, res, st = engine.query_fix(srcs)
     deg = np.diff(row_ptr)
-    t1 = int(np.ceil(np.ldexp(rmax, 62)))
+    t1 = np.uint64(int(np.ceil(np.ldexp(rmax, 62))))
+    thr = t1 * deg.astype(np.uint64)   # < 2^63: t1 ~ 4.5e11, degrees < 1e5
+    thr[deg == 0] = 1
     for i in range(len(srcs)):
         assert st[i]["ppr_sum_fix"] == 1 << 62
         assert int(ppr[i].sum()) == 1 << 62
-        assert (res[i].astype(object)[:2000] < (t1 * deg[:2000]).astype(object)).all()
+        assert (res[i] < thr).all()                      # algo.h:1012 for every node
         assert int(res[i].sum()) == st[i]["rsum_fix"]
     ppr2, _, _ = engine.query_fix(srcs[:8], want_residue=False)
     assert (ppr2 == ppr[:8]).all()
@@ -218,6 +222,32 @@ def test_full_size_webstanford_properties(engine, oracle):
     g = oracle.Graph(n, m, row_ptr, col)
     want, _, _ = oracle.twin_query(g, int(srcs[0]), rmax, omega, seed=SEED)
     assert (ppr[0] == want).all()
+    # ---- float side.  Tolerances: the estimate keeps |est - pi| <= eps * pi wherever pi >= 1/n (the FORA guarantee,
+    # algo.h:455-463; measured worst 0.25 of the allowed 0.5); L-inf against exact PPR <= 2e-5 (measured 5e-6: walk
+    # noise ~ sqrt(pi / omega)); against the FIFO-order oracle, itself such an estimate with its own walks, <= 4e-5.
+    # Both pushes stop with every residue under rmax * outdeg, so either rsum is below nnz * rmax = 0.227.
+    eps = 0.5
+    engine.build_index()
+    ppr_idx, _, st_idx = engine.query_fix(srcs[:4], with_idx=True, want_residue=False)
+    est_idx = oracle.fix_to_double(ppr_idx)
+    idx = engine.get_index()
+    for i in range(4):
+        s = int(srcs[i])
+        est = oracle.fix_to_double(ppr[i])
+        exact = oracle.power_iteration(g, s)
+        fifo, fst = oracle.query(g, s, rmax, omega, seed=SEED)
+        fifo_idx, fst_idx = oracle.query(g, s, rmax, omega, seed=SEED, index=idx)
+        big = exact >= 1.0 / n
+        for e, f, stats, fstats in ((est, fifo, st[i], fst), (est_idx[i], fifo_idx, st_idx[i], fst_idx)):
+            assert abs(e.sum() - 1.0) < 1e-12
+            assert np.abs(e - exact).max() <= 2e-5
+            assert (np.abs(e - exact)[big] / exact[big]).max() <= eps
+            assert (np.abs(f - exact)[big] / exact[big]).max() <= eps       # the oracle meets the same guarantee
+            assert np.abs(e - f).max() <= 4e-5
+            assert 0 < stats["rsum"] < col.size * rmax and 0 < fstats["rsum"] < col.size * rmax
+        assert st_idx[i]["n_idx_hit"] == st_idx[i]["n_walks"] == st[i]["n_walks"]      # same push, 100 % index hit
+        assert fst_idx["n_idx_hit"] == fst_idx["n_walks"]
+    engine.clear_index()
 
 
 @pytest.mark.parametrize("with_idx", [False, True])
