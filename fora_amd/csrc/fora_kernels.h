@@ -90,6 +90,7 @@ struct QState {       // per-slot accumulators
     unsigned long long pops, relax;
     unsigned long long n_walks, n_hit, n_rw, ppr_sum;
     uint32_t levels, dangling_source;
+    uint32_t tshift, pad_;       // bucketed push: the slot's current threshold is t1 << tshift (threshold rounds, see k_round_sweep)
 };
 
 struct Dev {
@@ -145,6 +146,8 @@ struct Dev {
     // gathers from [L & 1] while it writes the entries of the nodes it pops for level L + 1 into the other one
     uint64_t *inc_tab[2];
     unsigned long long *stamps; // diagnostic builds (-DFORA_STAMPS): cycles per kernel phase, [0..15] bin kernel, [16..31] accumulate
+    int32_t rounds;         // threshold rounds of the bucketed push (k_round_sweep); 1: the plain schedule
+    uint32_t *sw_count, *sw_done; // [slot * CSTRIDE] k_round_sweep: entries appended / workgroups finished (both return to 0)
     int32_t pop_next;       // k_accum<false>: pop the crossing nodes for the next level (0 on the last level of a capped run)
     uint64_t segq_cap;      // = n: a frontier holds each node at most once
     // Message buckets.  Every (slot, bin) bucket is cut into `sub` sub-buckets, one per producer workgroup of the slot
@@ -214,6 +217,11 @@ __device__ __forceinline__ uint64_t pop_value(uint64_t afix, uint64_t r, uint32_
     res_add = keep + (push - inc * deg);
     dang = 0;
     return inc;
+}
+
+// threshold unit of a round: t1 << k, saturating
+__device__ __forceinline__ uint64_t thr_unit(uint64_t t1, uint32_t k) {
+    return k == 0 ? t1 : ((t1 >> (63 - k)) ? (~0ull >> 1) : (t1 << k));
 }
 
 __device__ __forceinline__ void node_row(const Dev &d, uint32_t v, int64_t &beg, uint64_t &deg) {
@@ -381,6 +389,11 @@ __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
         d.fl[0][(uint64_t)q * d.n] = s;
         d.inc_tab[0][(uint64_t)q * d.segq_cap] = FIX_ONE;
         d.fl_count[0][q * CSTRIDE] = 1;
+        if (mode == 0 && d.rounds > 1) { // threshold rounds: start at t1 << (rounds - 1); the host reads the shift beside the frontier size
+            z.tshift = (uint32_t)d.rounds - 1;
+            d.fl_count[0][q * CSTRIDE + 1] = z.tshift;
+            d.fl_count[1][q * CSTRIDE + 1] = z.tshift;
+        }
     } else {
         d.residue[a] = FIX_ONE;
         unsigned long long i = atomicAdd(&d.wl_count[0], 1ull);
@@ -582,6 +595,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
     if (first_pass && blockIdx.x == 0 && threadIdx.x == 0) {
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
+        if (count) d.qs[q].levels++;          // levels in which the slot popped (this thread is the only writer in a launch)
     }
     if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
@@ -762,7 +776,6 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
         if (acc_dang) atomicAdd(&qs->dang[par], (unsigned long long)acc_dang);
         atomicAdd(&qs->pops, (unsigned long long)acc_pops);
         if (acc_relax) atomicAdd(&qs->relax, (unsigned long long)acc_relax);
-        qs->levels = (uint32_t)L + 1;
     }
 }
 
@@ -788,7 +801,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
     const uint32_t src = (uint32_t)d.src[q];
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
-    uint32_t last_level = 0;
+    uint32_t levels_run = 0;
     for (int done = 0; max_levels <= 0 || done < max_levels; done++, L++) {
         const int par = L & 1;
         uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
@@ -805,7 +818,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
         uint32_t *out = d.fl[par ^ 1] + slab;
         // ---- all pops of the level (algo.h:983-1002).  The entries of level L0 carry the residue already taken from
         // their nodes (see k_accum); later levels are collected by this kernel and take it here.
-        last_level = (uint32_t)L + 1;
+        levels_run++;
         for (uint32_t i = tid; i < count; i += TAIL_THREADS) {
             const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
             const uint64_t a = slab + v;
@@ -891,7 +904,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
         atomicAdd(&s->pops, (unsigned long long)acc_pops);
         if (acc_relax) atomicAdd(&s->relax, (unsigned long long)acc_relax);
     }
-    if (tid == 0 && last_level) d.qs[q].levels = last_level;
+    if (tid == 0 && levels_run) d.qs[q].levels += levels_run;
 }
 
 // grid = (bins of the pass, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
@@ -947,6 +960,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     const uint64_t bk0 = bi * sub * d.bk_cap; // sub-bucket x starts at bk0 + x * bk_cap
     const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
     const uint64_t *itab = TO_PPR ? nullptr : d.inc_tab[par] + (uint64_t)q * d.segq_cap;
+    const uint64_t t1q = TO_PPR ? 0 : thr_unit(d.t1, d.qs[q].tshift); // the slot's threshold unit in its current round
     // message forms: narrow push = 4-byte word (local target << SEG_BITS | frontier position), increment gathered from the
     // table; everything else = ONE 64-bit word in bk_inc: narrow walk results node id | weight << WPACK_SHIFT, wide
     // messages local target | value << BIN_SHIFT
@@ -980,7 +994,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 if (inc) {
                     const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
                     if (!TO_PPR) {
-                        const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                        const uint64_t thr = node_thr(t1q, d.deg[w]);
                         cross = old < thr && old + inc >= thr; // increments are positive: exactly one add crosses
                     }
                 }
@@ -1078,7 +1092,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 const uint64_t nw = old[k] + v[k];
                 bool cross = false;
                 if (!TO_PPR) {
-                    const uint64_t thr = node_thr(d.t1, dg[k]);
+                    const uint64_t thr = node_thr(t1q, dg[k]);
                     cross = pop && old[k] < thr && nw >= thr; // algo.h:1012
                 }
                 // this workgroup owns [node0, node0 + BIN_SIZE) of slot q; a crossing node gives its residue to the
@@ -1128,6 +1142,61 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     }
     STAMP(20);
     STAMP_FLUSH(16);
+    }
+}
+
+// ---- threshold rounds.  A level-synchronous push pops a node the level after it crosses its threshold, with whatever
+// it has collected by then; the FIFO of algo.h:980-1017 lets it collect more before its turn, so it moves more mass
+// per relaxed edge.  Rounds give that back: a slot first runs its levels against 2^(rounds-1) times the threshold
+// (every pop there carries at least that much more per edge); when its frontier runs dry, this kernel halves the
+// threshold and sweeps the slot's residue slab once for every node at or over the new one -- they become the next
+// frontier, as (node, residue) entries like k_accum's.  Two rounds (2x, then 1x) cut the relaxations of the ws-sized
+// headline graph from 1.27x to 1.05x of the sequential FIFO's.  Exit condition and invariants are those of algo.h:1012.
+// grid = (X, nq), after the accumulate of level L.  Every workgroup of a slot takes the same decision: nothing below
+// touches the frontier count before the slot's LAST workgroup is done.
+__global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
+    const int q = blockIdx.y;
+    const int np = (L & 1) ^ 1;
+    QState *qs = &d.qs[q];
+    const uint32_t ts = qs->tshift;
+    if (ts == 0 || d.fl_count[np][q * CSTRIDE] != 0) return; // last round, or the slot still has a frontier
+    const int lane = threadIdx.x & 63;
+    const uint64_t unit = thr_unit(d.t1, ts - 1);
+    const uint64_t slab = (uint64_t)q * d.n;
+    const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        const uint32_t v = c * BLOCK + threadIdx.x;
+        uint64_t r = 0;
+        bool in = false;
+        if (v < (uint32_t)d.n) {
+            r = d.residue[slab + v];
+            in = r && r >= node_thr(unit, d.deg[v]);
+        }
+        const unsigned long long mask = __ballot(in);
+        if (!mask) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&d.sw_count[q * CSTRIDE], (uint32_t)__popcll(mask));
+        base = __shfl(base, 0);
+        if (in) {
+            d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
+            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            if (pos < (uint32_t)d.n) { d.fl[np][slab + pos] = v; d.inc_tab[np][(uint64_t)q * d.segq_cap + pos] = r; }
+            else atomicOr(d.err, ERR_WL_OVERFLOW);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(&d.sw_done[q * CSTRIDE], 1u);
+        if (ticket == gridDim.x - 1) { // the slot's last workgroup publishes the new frontier and the new round
+            __threadfence();
+            const uint32_t cnt = atomicExch(&d.sw_count[q * CSTRIDE], 0u);
+            d.fl_count[np][q * CSTRIDE] = cnt;
+            qs->tshift = ts - 1;
+            d.fl_count[0][q * CSTRIDE + 1] = ts - 1;
+            d.fl_count[1][q * CSTRIDE + 1] = ts - 1;
+            atomicExch(&d.sw_done[q * CSTRIDE], 0u);
+        }
     }
 }
 

@@ -132,6 +132,9 @@ typedef struct {
     int64_t relax;
 } orc_twin_push_stats;
 /* residue, ppr: n u64, zeroed by the callee.  level_sizes (optional, cap entries). */
+/* threshold rounds of orc_twin_push / orc_twin_query (the engine's option "rounds"; default 1) */
+void orc_twin_set_rounds(int rounds);
+int orc_twin_get_rounds(void);
 int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
                   double alpha, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *st,
                   int64_t *level_sizes, int64_t cap);

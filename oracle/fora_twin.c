@@ -105,6 +105,15 @@ static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, u
     }
 }
 
+/* Threshold rounds of the HIP push (fora_kernels.h k_round_sweep): the levels first run against 2^(rounds-1) times the
+ * threshold; whenever the frontier runs dry the threshold is halved and every node at or over the new one (found by
+ * a sweep over the residues) forms the next frontier, down to the threshold of algo.h:1012 itself.  rounds = 1 is the
+ * plain level-synchronous schedule and the engine's default (option "rounds"). */
+static int g_twin_rounds = 1;
+void orc_twin_set_rounds(int rounds) { g_twin_rounds = rounds < 1 ? 1 : rounds > 16 ? 16 : rounds; }
+int orc_twin_get_rounds(void) { return g_twin_rounds; }
+static uint64_t thr_unit(uint64_t t1, int k) { return k == 0 ? t1 : ((t1 >> (63 - k)) ? (UINT64_MAX >> 1) : (t1 << k)); }
+
 /* Twin of forward_local_update_linear (algo.h:954-1018). */
 int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
                   double alpha, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *st,
@@ -123,8 +132,19 @@ int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t
     uint64_t *inc = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
     residue[s] = ORC_FIX_ONE; /* algo.h:976 */
     frontier[0] = s;          /* the source is pushed unconditionally (algo.h:973,980) */
-    twin_levels(row_ptr, col, s, orc_twin_rmax_fix(rmax), orc_twin_alpha_fix(alpha), residue, ppr,
-                frontier, 1, next, inc, &z, level_sizes, cap, 0);
+    {
+        const uint64_t t1 = orc_twin_rmax_fix(rmax), afix = orc_twin_alpha_fix(alpha);
+        int64_t fn = 1;
+        for (int k = g_twin_rounds - 1; k >= 0; k--) {
+            const uint64_t unit = thr_unit(t1, k);
+            if (k != g_twin_rounds - 1) { /* next round: every node at or over the halved threshold */
+                fn = 0;
+                for (int32_t v = 0; v < n; v++)
+                    if (residue[v] && residue[v] >= node_thr(unit, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
+            }
+            twin_levels(row_ptr, col, s, unit, afix, residue, ppr, frontier, fn, next, inc, &z, level_sizes, cap, 0);
+        }
+    }
     uint64_t reserved = 0;
     for (int32_t v = 0; v < n; v++) reserved += ppr[v];
     z.rsum_fix = ORC_FIX_ONE - reserved; /* == sum of residue, exactly */

@@ -273,6 +273,11 @@ def twin_walk_counts(g, residue, rsum_fix, omega, alpha=0.2, opt=False):
     return N, out
 
 
+def twin_set_rounds(rounds):
+    """Threshold rounds of the twin's push (the engine's option \"rounds\", default 1)."""
+    lib().orc_twin_set_rounds(C.c_int(int(rounds)))
+
+
 def twin_query(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None):
     residue = np.zeros(g.n, dtype=np.uint64)
     ppr = np.zeros(g.n, dtype=np.uint64)

@@ -354,6 +354,40 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3, 5])
+def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds):
+    """Threshold rounds of the push (k_round_sweep; option "rounds", default 1 = off): 2^(rounds-1) x the threshold
+    first, halved whenever a slot's frontier runs dry.  Every setting equals the twin running the same schedule bit for
+    bit, ends with the exit condition of algo.h:1012, and more rounds never relax more edges than the plain schedule
+    (they need more, smaller levels though, which is why the default stays at 1: DESIGN.md 5.4)."""
+    g = small_dangling
+    rmax, omega = _load(engine, g, epsilon=0.5)
+    srcs = np.concatenate([pick_sources(g, 6, 71), pick_sources(g, 1, 72, want_dangling=True)])
+    engine.set_option("rounds", 1)
+    _, _, st1 = engine.push(srcs)
+    engine.set_option("rounds", rounds)
+    oracle.twin_set_rounds(rounds)
+    try:
+        rsv, res, st = engine.push(srcs)
+        t1 = int(np.ceil(np.ldexp(rmax, 62)))
+        for i, s in enumerate(srcs):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+            assert int(rsv[i].sum()) + int(res[i].sum()) == oracle.FIX_ONE
+            thr = (t1 * g.deg).astype(np.uint64)
+            thr[g.deg == 0] = 1
+            assert (res[i] < thr).all()
+        assert sum(int(x["relax"]) for x in st) <= sum(int(x["relax"]) for x in st1)
+        ppr, _, stq = engine.query_fix(srcs[:3], want_residue=False)
+        for i in range(3):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+            assert (ppr[i] == want).all() and stq[i]["n_walks"] == wst["n_walks"]
+    finally:
+        engine.reset_options()
+        oracle.twin_set_rounds(1)
+
+
 def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
     """Opt-in second lane (push of batch k+1 overlapping walks of batch k) gives the same bits."""
     g = small
