@@ -362,7 +362,7 @@ def main():
                 counts_from = "sequential FIFO oracle (CPU), same sources"
                 out["cpu_baseline"] = cpu
                 threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
-                if threads > 1:
+                if threads > 1 and cpu["value"] * args.cpu_seconds >= 10:  # every thread runs at least one whole query: only when one fits the budget ten times over
                     out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
             elif per_query_guess <= 5.0:  # N > 1: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
                 t1 = time.perf_counter()

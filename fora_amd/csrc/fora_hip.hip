@@ -37,7 +37,7 @@ struct Tunables {
     int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
     int64_t tiny = 512;          // k_accum: buckets up to this many messages go by direct atomics
     int64_t xb = 0, ax = 0, wx = 0; // workgroups per slot: bin kernel / slab sweeps / walks (0: from the slot count)
-    int64_t tail = 1024;         // frontier size from which k_push_tail takes over (0: never)
+    int64_t tail = 32768;        // frontier size (largest slot) from which k_push_tail takes over (0: never)
     int64_t tail_always = 0;     // 1: do not wait for the frontier to have been large first (tests)
     int64_t select_compact = -1; // top-k select over compacted non-zeros: -1 by graph size, 0 never, 1 always
     int64_t rounds = 1;          // threshold rounds of the bucketed push (k_round_sweep): 2^(rounds-1) x the threshold first; 1: plain.
@@ -499,7 +499,9 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     int L = 0;
     const int nq = d.nq;
     const unsigned xb = c->binned ? c->sub : 1u; // producer workgroups per slot = sub-buckets per bucket (Dev::bk_w); ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
-    // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, 3000 queries: off 3403 q/s, 256: 3431, 1024: 3461, 4096: 3377, 16384: 3269
+    // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, push of 1000 queries (round 2's
+    // tail kernel: no agent-scope fences, 4 relaxations in flight per lane): 1024: 86.3 ms, 4096: 85.2, 16384: 82.5,
+    // 32768: 81.9, 131072: 163 (one workgroup per slot cannot feed the peak levels)
     const uint32_t tail_max = (uint32_t)std::max<int64_t>(0, c->opt_.tail);
     bool past_peak = c->opt_.tail_always == 1; // tests: do not wait for the frontier to have been large first
     for (;; L++) {

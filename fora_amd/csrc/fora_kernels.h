@@ -787,7 +787,14 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
 // loads, so no stale L1 line is ever observed).  Integer adds commute: same bits as the bucketed levels and the twin.
 // grid = nq, TAIL_THREADS threads.  L0: first level to run (its entries carry their residue, see k_accum);
 // max_levels: stop after that many more (0: until empty).
-constexpr int TAIL_THREADS = 1024;
+#ifndef FORA_TAIL_THREADS
+#define FORA_TAIL_THREADS 1024
+#endif
+#ifndef FORA_TAIL_EPT
+#define FORA_TAIL_EPT 4
+#endif
+constexpr int TAIL_THREADS = FORA_TAIL_THREADS;
+constexpr int TAIL_EPT = FORA_TAIL_EPT; // relaxations a lane keeps in flight
 __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int max_levels) {
     __shared__ int64_t s_ebeg[TAIL_THREADS];
     __shared__ uint64_t s_inc[TAIL_THREADS];
@@ -802,6 +809,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
     uint32_t levels_run = 0;
+    // Visibility inside the workgroup: every mutable word is read and written with atomics or L1-bypassing loads, plain
+    // stores (frontier lists, increments) are complete at the next __syncthreads() -- no agent-scope fence is needed
+    // (three __threadfence() per level cost more than the level's work on small frontiers).
     for (int done = 0; max_levels <= 0 || done < max_levels; done++, L++) {
         const int par = L & 1;
         uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
@@ -834,9 +844,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
             acc_pops++;
             acc_relax += deg;
         }
-        __threadfence();
         __syncthreads();
-        // ---- relaxations, a tile of TAIL_THREADS frontier nodes at a time (algo.h:1003-1016)
+        // ---- relaxations, a tile of TAIL_THREADS frontier nodes at a time (algo.h:1003-1016); a lane takes TAIL_EPT
+        // consecutive edges of the tile and keeps their gathers, then their adds, in flight together
         for (uint32_t tbase = 0; tbase < count; tbase += TAIL_THREADS) {
             const uint32_t i = tbase + tid;
             uint32_t cnt = 0;
@@ -845,8 +855,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
                 int64_t beg; uint64_t deg;
                 node_row(d, v, beg, deg);
                 s_ebeg[tid] = beg;
-                s_inc[tid] = __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
-                cnt = (uint32_t)deg;
+                const uint64_t inc = __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
+                s_inc[tid] = inc;
+                cnt = inc ? (uint32_t)deg : 0u;
             }
             uint32_t wtot;
             const uint32_t wx = wave_excl_scan(cnt, wtot);
@@ -858,22 +869,46 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
             s_pref[tid] = before + wx;
             if (tid == 0) s_pref[TAIL_THREADS] = total;
             __syncthreads();
-            for (uint32_t e = tid; e < total; e += TAIL_THREADS) {
-                uint32_t lo = 0, hi = TAIL_THREADS;
+            for (uint32_t cb = 0; cb < total; cb += TAIL_THREADS * TAIL_EPT) {
+                const uint32_t e0 = cb + tid * TAIL_EPT;
+                uint32_t lo = 0;
+                if (e0 < total) {
+                    uint32_t hi = TAIL_THREADS;
 #pragma unroll
-                for (int it = 0; it < 10; it++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                    for (int it = 0; it < (TAIL_THREADS == 1024 ? 10 : TAIL_THREADS == 512 ? 9 : 8); it++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= e0) lo = mid; else hi = mid;
+                    }
                 }
-                while (s_pref[lo + 1] <= e) lo++; // nodes without edges
-                const uint64_t inc = s_inc[lo];
-                if (!inc) continue;
-                const uint32_t w = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
-                const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)inc);
-                const uint64_t thr = node_thr(d.t1, d.deg[w]);
-                if (old < thr && old + inc >= thr) { // crossed in this level: next frontier (algo.h:1012-1015)
-                    const uint32_t pos = atomicAdd(&s_next, 1u);
-                    if (pos < (uint32_t)d.n) out[pos] = w; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                uint32_t w[TAIL_EPT], dg[TAIL_EPT];
+                uint64_t inc[TAIL_EPT], old[TAIL_EPT];
+#pragma unroll
+                for (int k = 0; k < TAIL_EPT; k++) {
+                    const uint32_t e = e0 + k;
+                    w[k] = 0xFFFFFFFFu; inc[k] = 0;
+                    if (e < total) {
+                        while (s_pref[lo + 1] <= e) lo++; // nodes without edges
+                        inc[k] = s_inc[lo];
+                        w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < TAIL_EPT; k++) {
+                    old[k] = 0; dg[k] = 0;
+                    if (w[k] != 0xFFFFFFFFu) {
+                        old[k] = atomicAdd((unsigned long long *)&d.residue[slab + w[k]], (unsigned long long)inc[k]);
+                        dg[k] = d.deg[w[k]];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < TAIL_EPT; k++) {
+                    if (w[k] != 0xFFFFFFFFu) {
+                        const uint64_t thr = node_thr(d.t1, dg[k]);
+                        if (old[k] < thr && old[k] + inc[k] >= thr) { // crossed in this level: next frontier (algo.h:1012-1015)
+                            const uint32_t pos = atomicAdd(&s_next, 1u);
+                            if (pos < (uint32_t)d.n) out[pos] = w[k]; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -888,13 +923,11 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
                 if (pos < (uint32_t)d.n) out[pos] = src; else atomicOr(d.err, ERR_WL_OVERFLOW);
             }
         }
-        __threadfence();
         __syncthreads();
         if (tid == 0) {
             d.fl_count[par ^ 1][q * CSTRIDE] = s_next;
             d.fl_count[par][q * CSTRIDE] = 0;
         }
-        __threadfence();
         __syncthreads();
     }
     acc_res = wave_sum(acc_res); acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
@@ -1034,29 +1067,34 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     // sub-buckets into 64-message units dealt round-robin to the waves -- no idle lanes but a 7-step search per unit --
     // was measured: accumulate 43 -> 59 ms per 1000 ws queries.)
     constexpr int ACC_UNROLL = 4;
-    for (uint32_t x = wid; x < sub; x += NW) {
-        const uint32_t n_x = s_scnt[x];
-        const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
-        for (uint32_t i0 = 0; i0 < n_x; i0 += 64 * ACC_UNROLL) {
-            uint32_t mw[ACC_UNROLL];
-            uint64_t mi[ACC_UNROLL];
+    // two sub-buckets (x and x + NW) per trip: 2 * ACC_UNROLL loads in flight per lane, half the dependent round trips
+    for (uint32_t x = wid; x < sub; x += 2 * NW) {
+        const uint32_t xb = x + NW < sub ? x + NW : x;
+        const uint32_t n_a = s_scnt[x], n_b = x + NW < sub ? s_scnt[xb] : 0;
+        const uint64_t at_a = bk0 + (uint64_t)x * d.bk_cap, at_b = bk0 + (uint64_t)xb * d.bk_cap;
+        const uint32_t n_max = n_a > n_b ? n_a : n_b;
+        for (uint32_t i0 = 0; i0 < n_max; i0 += 64 * ACC_UNROLL) {
+            uint32_t mw[2 * ACC_UNROLL];
+            uint64_t mi[2 * ACC_UNROLL];
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
-                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[at0 + (i < n_x ? i : 0)]);
+                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[at_a + (i < n_a ? i : 0)]);
+                mw[ACC_UNROLL + k] = packed ? 0u : NT_LOAD(&d.bk_w[at_b + (i < n_b ? i : 0)]);
             }
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
-                mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at0 + (i < n_x ? i : 0)]);
+                mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at_a + (i < n_a ? i : 0)]);
+                mi[ACC_UNROLL + k] = gather ? itab[mw[ACC_UNROLL + k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at_b + (i < n_b ? i : 0)]);
             }
 #pragma unroll
-            for (int k = 0; k < ACC_UNROLL; k++) {
-                const uint32_t i = i0 + k * 64 + lane;
+            for (int k = 0; k < 2 * ACC_UNROLL; k++) {
+                const uint32_t i = i0 + (k % ACC_UNROLL) * 64 + lane;
                 uint32_t local = mw[k] >> SEG_BITS;
                 uint64_t inc = mi[k];
                 if (packed) { local = (uint32_t)inc; inc >>= pshift; }
-                if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
+                if (i < (k < ACC_UNROLL ? n_a : n_b) && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
             }
         }
     }
