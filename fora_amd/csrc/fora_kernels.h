@@ -1067,34 +1067,29 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     // sub-buckets into 64-message units dealt round-robin to the waves -- no idle lanes but a 7-step search per unit --
     // was measured: accumulate 43 -> 59 ms per 1000 ws queries.)
     constexpr int ACC_UNROLL = 4;
-    // two sub-buckets (x and x + NW) per trip: 2 * ACC_UNROLL loads in flight per lane, half the dependent round trips
-    for (uint32_t x = wid; x < sub; x += 2 * NW) {
-        const uint32_t xb = x + NW < sub ? x + NW : x;
-        const uint32_t n_a = s_scnt[x], n_b = x + NW < sub ? s_scnt[xb] : 0;
-        const uint64_t at_a = bk0 + (uint64_t)x * d.bk_cap, at_b = bk0 + (uint64_t)xb * d.bk_cap;
-        const uint32_t n_max = n_a > n_b ? n_a : n_b;
-        for (uint32_t i0 = 0; i0 < n_max; i0 += 64 * ACC_UNROLL) {
-            uint32_t mw[2 * ACC_UNROLL];
-            uint64_t mi[2 * ACC_UNROLL];
+    for (uint32_t x = wid; x < sub; x += NW) {
+        const uint32_t n_x = s_scnt[x];
+        const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
+        for (uint32_t i0 = 0; i0 < n_x; i0 += 64 * ACC_UNROLL) { // (two sub-buckets per trip, 8 loads in flight: no gain measured)
+            uint32_t mw[ACC_UNROLL];
+            uint64_t mi[ACC_UNROLL];
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
-                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[at_a + (i < n_a ? i : 0)]);
-                mw[ACC_UNROLL + k] = packed ? 0u : NT_LOAD(&d.bk_w[at_b + (i < n_b ? i : 0)]);
+                mw[k] = packed ? 0u : NT_LOAD(&d.bk_w[at0 + (i < n_x ? i : 0)]);
             }
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
-                mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at_a + (i < n_a ? i : 0)]);
-                mi[ACC_UNROLL + k] = gather ? itab[mw[ACC_UNROLL + k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at_b + (i < n_b ? i : 0)]);
+                mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at0 + (i < n_x ? i : 0)]);
             }
 #pragma unroll
-            for (int k = 0; k < 2 * ACC_UNROLL; k++) {
-                const uint32_t i = i0 + (k % ACC_UNROLL) * 64 + lane;
+            for (int k = 0; k < ACC_UNROLL; k++) {
+                const uint32_t i = i0 + k * 64 + lane;
                 uint32_t local = mw[k] >> SEG_BITS;
                 uint64_t inc = mi[k];
                 if (packed) { local = (uint32_t)inc; inc >>= pshift; }
-                if (i < (k < ACC_UNROLL ? n_a : n_b) && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
+                if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
             }
         }
     }
