@@ -1729,12 +1729,13 @@ __device__ __forceinline__ int32_t walk_one(const Dev &d, uint32_t start, uint64
 // bins them by target range (LDS counters), reserves bucket space with ONE global atomic per
 // (flush, bin), and stores them.  k_accum then reduces every (slot, bin) bucket in LDS.
 #ifndef FORA_STAGE
-#define FORA_STAGE 448
+#define FORA_STAGE 320
 #endif
 #ifndef FORA_WALK_WPE
-#define FORA_WALK_WPE 5
+#define FORA_WALK_WPE 6
 #endif
-constexpr int STAGE = FORA_STAGE; // results per wave: the largest stage that still fits 5 workgroups per CU (8-byte packed results, register cap below); 320 -> 520 ms, 448 -> 508, 480 -> 508 per 3000 ws queries
+constexpr int STAGE = FORA_STAGE; // results per wave.  Round 2 (1000 ws queries, walk kernel): 448 at 5 waves per SIMD 160.0 ms, 320 at 6 (80 VGPRs, 26 KB of LDS) 154.8,
+                                  // 256 at "7" (the compiler stays at 83 VGPRs = 5) 165.0, 192 at 6 160.3; 4 waves per SIMD 180.2
 struct WaveStage {
     uint64_t *pk;    // [STAGE]
     uint32_t *bcnt;  // [MAX_BINS]
