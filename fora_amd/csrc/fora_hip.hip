@@ -112,7 +112,7 @@ struct fora_ctx {
     int nbins = 0, pbins = 0; // bins of the graph; bins per pass (bucket-array stride)
     uint32_t *d_fl[2] = {nullptr, nullptr}, *d_fl_count = nullptr; // fl_count: [2][B]
     uint64_t *d_inc_tab[2] = {nullptr, nullptr};
-    uint32_t *d_ov_w = nullptr, *d_ov_count = nullptr; // bucket overflow list
+    uint32_t *d_ov_w = nullptr, *d_ov_count = nullptr, *d_ov_bin = nullptr; // bucket overflow list, its size, its entries per bin [2][B][nbins]
     uint64_t *d_ov_inc = nullptr;
     uint32_t ov_cap = 0;
     uint32_t *d_bk_w = nullptr, *d_bk_count = nullptr;
@@ -199,7 +199,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
     dfree(c->d_nz_counts);
     c->topk_cap = 0;
-    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count);
+    dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
@@ -252,9 +252,12 @@ static uint32_t want_bk_cap(const fora_ctx *c) {
     if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
     return 163840; // walk results: ~omega*rsum/nbins per bucket (ws: ~110 k)
 }
-static uint32_t want_bk_cap_wide(const fora_ctx *c) { // push messages only (walk results go by direct atomics in the wide layout)
+static uint32_t want_bk_cap_wide(const fora_ctx *c) { // messages per (slot, bin) bucket: push increments and indexed walk results (online ones go by direct atomics)
     if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
-    return 196608; // also holds the indexed walk results (~omega*rsum/nbins per bucket)
+    // a dense level relaxes about every edge once: nnz / nbins messages per bin on average (Twitter-2010-sized: 289 k),
+    // hubs' bins beyond that use the overflow list; 196608 covers the indexed walk results (~omega*rsum/nbins per bucket)
+    const uint64_t nbins = ((uint64_t)c->n + BIN_SIZE - 1) >> BIN_SHIFT;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(196608, (uint64_t)(1.4 * (double)c->nnz / (double)std::max<uint64_t>(1, nbins))), 1u << 26);
 }
 
 struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32_t bk_cap, sub; uint64_t segq_cap; bool binned; };
@@ -262,7 +265,10 @@ struct WsPlan { uint64_t segs, wits, scratch, per_slot; int nbins, pbins; uint32
 // sub-buckets per (slot, bin) = producer workgroups per slot (Dev::bk_w): ~16 k producer workgroups per launch
 static uint32_t want_sub(const fora_ctx *c, int slots) {
     if (c->opt_.xb > 0) return (uint32_t)std::min<int64_t>(c->opt_.xb, MAX_SUB);
-    if (want_wide(c)) return slots >= 32 ? 32u : 64u; // 512-thread producers, 2 resident per CU; LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515, 128 -> 539
+    // wide: 512-thread producers, 2-3 resident per CU.  LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515,
+    // 128 -> 539; Twitter-sized, 12 slots, 24 queries: 32 -> 2438 ms, 64 -> 2010, 128 -> 1576 (few slots: the tiles of a level
+    // have to be dealt to many workgroups)
+    if (want_wide(c)) return slots >= 32 ? 32u : (uint32_t)MAX_SUB;
     return (uint32_t)std::min(MAX_SUB, std::max(16, 16384 / std::max(1, slots)));
 }
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
@@ -338,7 +344,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (B == 0) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
-        uint64_t budget = (uint64_t)(fr * 0.4); // a second lane may hold its own workspace
+        uint64_t budget = (uint64_t)(fr * (c->opt_.pipeline == 1 ? 0.4 : 0.75)); // with option pipeline a second lane holds its own workspace
         B = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, budget / p.per_slot)); // ws, 1000 queries: 2845 q/s at 256, 3035 at 512, 3101 at 1000
     }
     B = std::max(1, B);
@@ -367,6 +373,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_ov_w, (uint64_t)B * c->ov_cap * 4));
         HIPCHK(c, hipMalloc(&c->d_ov_inc, (uint64_t)B * c->ov_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_ov_count, 2 * (size_t)B * 4 * CSTRIDE));
+        HIPCHK(c, hipMalloc(&c->d_ov_bin, 2 * (size_t)B * p.nbins * 4));
         if (!want_wide(c)) HIPCHK(c, hipMalloc(&c->d_bk_w, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 4)); // wide: one 64-bit word per message in bk_inc
         HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * p.sub * 4));
@@ -435,6 +442,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.sw_count = c->d_sw; d.sw_done = c->d_sw ? c->d_sw + (size_t)c->B * CSTRIDE : nullptr;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
     d.ov_count[0] = c->d_ov_count; d.ov_count[1] = c->d_ov_count ? c->d_ov_count + (size_t)c->B * CSTRIDE : nullptr;
+    d.ov_bin[0] = c->d_ov_bin; d.ov_bin[1] = c->d_ov_bin ? c->d_ov_bin + (size_t)c->B * c->nbins : nullptr;
     d.bk_w = c->d_bk_w; d.bk_inc = c->d_bk_inc; d.bk_count = c->d_bk_count; d.bk_cap = c->bk_cap; d.sub = c->sub;
     if (with_idx) { d.rw_idx = c->d_rw_idx; d.idx_off = c->d_idx_off; d.idx_cnt = c->d_idx_cnt; }
     return d;
@@ -613,6 +621,7 @@ int reset_binned_counters(fora_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_fl_count, 0, (size_t)c->B * 2 * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * c->sub * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ov_bin, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
     return FORA_OK;
 }
 

@@ -166,6 +166,7 @@ struct Dev {
     uint32_t *ov_w;         // [slot][ov_cap]
     uint64_t *ov_inc;       // [slot][ov_cap]
     uint32_t *ov_count[2];  // [slot * CSTRIDE]
+    uint32_t *ov_bin[2];    // [slot][nbins] entries of the list that belong to the bin: k_accum scans the list only when its own count is not zero
     uint32_t ov_cap;
     int32_t wide;           // != 0: nbins > MAX_BINS, push messages are (bk_w = local target, bk_inc = increment)
 };
@@ -758,6 +759,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
                     if (oi < d.ov_cap) {
                         d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
                         d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
+                        atomicAdd(&d.ov_bin[par][(uint64_t)q * d.nbins + bin_lo + b], 1u);
                     } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
                 }
             }
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __shared__ uint32_t s_gbase;
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
     __shared__ uint32_t s_nlist;
-    __shared__ uint32_t s_scnt[MAX_SUB], s_total;
+    __shared__ uint32_t s_scnt[MAX_SUB], s_total, s_ovn;
     const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
     const int b = d.bin_lo + lb;
     const int par = L & 1;
@@ -976,7 +978,16 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
             t += c;
         }
         t = (uint32_t)wave_sum((uint64_t)t);
-        if (threadIdx.x == 0) { s_total = t; s_nlist = 0; }
+        if (threadIdx.x == 0) {
+            s_total = t; s_nlist = 0;
+            uint32_t o = 0;
+            if (!TO_PPR && d.ov_bin[par][(uint64_t)q * d.nbins + b]) { // a hub's bin at a dense level; usually none
+                d.ov_bin[par][(uint64_t)q * d.nbins + b] = 0;
+                o = d.ov_count[par][q * CSTRIDE];
+                if (o > d.ov_cap) o = d.ov_cap;
+            }
+            s_ovn = o;
+        }
     }
     const uint32_t s = (uint32_t)d.src[q];
     const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
@@ -984,8 +995,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     __syncthreads();
     const uint32_t cnt = s_total;
     if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
-    uint32_t ovn = TO_PPR ? 0 : d.ov_count[par][q * CSTRIDE];
-    if (ovn > d.ov_cap) ovn = d.ov_cap;
+    const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
     if (cnt == 0 && dm == 0 && ovn == 0) return;
     uint32_t *fl_next = d.fl[par ^ 1] + slab;
     uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
