@@ -641,6 +641,14 @@ int reset_batch_state(fora_ctx *c, int nq, const int32_t *sources) {
 
 enum { RUN_PUSH_ONLY = 1 };
 
+// slots per batch for nq queries on B slots: the fewest batches, all about the same size (1000 queries on 140 slots: 8 x 125,
+// not 7 x 140 + 20 -- a small trailing batch costs almost a full batch's level latencies)
+static int even_batch(int nq, int B) {
+    if (nq <= B || B <= 0) return std::max(nq, 1);
+    const int nbatch = (nq + B - 1) / B;
+    return (nq + nbatch - 1) / nbatch;
+}
+
 // refinement launches after k_walk_alloc: indexed walks, online walks, and the accumulate of their results
 void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t round, int nzh) {
     const dim3 wg(walk_grid_x(c, nq), nq);
@@ -872,8 +880,9 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
         return FORA_OK;
     };
     int k = 0;
-    for (int b0 = 0; b0 < nq; b0 += c->B, k++) {
-        const int nb = std::min(c->B, nq - b0);
+    const int per = even_batch(nq, c->B);
+    for (int b0 = 0; b0 < nq; b0 += per, k++) {
+        const int nb = std::min(per, nq - b0);
         fora_ctx *lane = lanes[k & 1];
         // the lane's previous batch must be drained before its workspace is reused
         for (size_t i = 0; i < inflight.size();) {
@@ -1355,8 +1364,9 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
     const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
     std::vector<uint8_t> active;
     std::vector<unsigned long long> above;
-    for (int b0 = 0; b0 < nq; b0 += c->B) {
-        const int nb = std::min(c->B, nq - b0);
+    const int per = even_batch(nq, c->B);
+    for (int b0 = 0; b0 < nq; b0 += per) {
+        const int nb = std::min(per, nq - b0);
         const int hb = ev_begin(c, 5);
         rc = reset_batch_state(c, nb, sources + b0);
         if (rc) return rc;
@@ -1512,8 +1522,9 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
     std::vector<uint8_t> active;
     std::vector<unsigned long long> above;
     std::vector<uint32_t> failv;
-    for (int b0 = 0; b0 < nq; b0 += c->B) {
-        const int nb = std::min(c->B, nq - b0);
+    const int per = even_batch(nq, c->B);
+    for (int b0 = 0; b0 < nq; b0 += per) {
+        const int nb = std::min(per, nq - b0);
         const int hb = ev_begin(c, 5);
         rc = reset_batch_state(c, nb, sources + b0);
         if (rc) return rc;
@@ -1653,8 +1664,9 @@ static int power_iteration_batch_impl(fora_ctx *c, const int32_t *sources, int n
         HIPCHK(c, hipMalloc(&c->d_topk_sc, (size_t)c->B * k * 8));
         c->topk_cap = c->B * k;
     }
-    for (int b0 = 0; b0 < nq; b0 += c->B) {
-        const int nb = std::min(c->B, nq - b0);
+    const int per = even_batch(nq, c->B);
+    for (int b0 = 0; b0 < nq; b0 += per) {
+        const int nb = std::min(per, nq - b0);
         const int hb = ev_begin(c, 5);
         rc = reset_batch_state(c, nb, sources + b0);
         if (rc) return rc;
