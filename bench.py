@@ -404,13 +404,13 @@ def main():
         if tm["push_expand_launches"]:
             e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
             p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
-            launches = tm["push_expand_launches"]
+            launches = tm["push_expand_launches"] + tm["push_tail_launches"]  # bin-kernel launches (levels x passes) + the tail launch per batch
             bucketed = tm["push_accum_launches"] > 0
             # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
             # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
             # relaxation, credited once against the sum of both kernels' durations
             alg_bytes = (24.0 * e_unit + (52.0 * p_unit if bucketed else 0.0)) * q_timed
-            step_ms = tm["push_expand_ms"] + tm["push_accum_ms"]
+            step_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"]
             avg_ms = step_ms / launches
             achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
             traffic = None
@@ -432,9 +432,11 @@ def main():
                     traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
                                   for k in keys) / max(1, n_launch)
                     traffic_note = pmc.get("_note")
-            by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / launches}
+            by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / max(1, tm["push_expand_launches"])}
             if bucketed:
                 by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
+            if tm["push_tail_launches"]:
+                by_kernel["k_push_tail"] = tm["push_tail_ms"] / tm["push_tail_launches"]
             if tm["push_pop_launches"]:
                 by_kernel["k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
             out["roofline"] = {
@@ -455,7 +457,7 @@ def main():
             }
         walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
         out["phases"] = {
-            "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"],
+            "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
             "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "walk_accum_ms": tm["walk_accum_ms"], "other_ms": tm["other_ms"],
             "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
             "walks": tm["walks"], "walk_steps": tm["walk_steps"],

@@ -20,7 +20,7 @@ namespace {
 
 struct EvPair {
     hipEvent_t a, b;
-    int kind; // 0 pop, 1 expand, 2 walk_alloc, 3 walk, 4 other, 5 batch, 6 accum, 7 walk accum, 8 round sweep
+    int kind; // 0 pop, 1 expand, 2 walk_alloc, 3 walk, 4 other, 5 batch, 6 accum, 7 walk accum, 8 round sweep, 9 tail
 };
 
 } // namespace
@@ -477,6 +477,7 @@ void ev_collect(fora_ctx *c) { // call after the stream is idle
         case 5: c->timing.batch_ms += ms; c->timing.batches++; break;
         case 6: c->timing.push_accum_ms += ms; c->timing.push_accum_launches++; break;
         case 7: c->timing.walk_accum_ms += ms; break;
+        case 9: c->timing.push_tail_ms += ms; c->timing.push_tail_launches++; break;
         case 8: c->timing.push_accum_ms += ms; break; // k_round_sweep: part of the level's accumulate time, not a launch of its own in the counts
         }
     }
@@ -571,7 +572,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 const int next = L + 1;
                 const int remaining = level_cap > 0 ? level_cap - next : 0;
                 if (level_cap <= 0 || remaining > 0) {
-                    int h = ev_begin(c, 1);
+                    int h = ev_begin(c, 9);
                     hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, d, next, remaining);
                     ev_end(c, h);
                     c->timing.levels++;
@@ -1726,6 +1727,7 @@ int fora_hip_get_timing(fora_ctx *c, fora_timing *out) {
         out->push_accum_launches += w.push_accum_launches; out->walk_launches += w.walk_launches; out->batches += w.batches;
         out->pops += w.pops; out->relax += w.relax; out->walks += w.walks; out->walk_steps += w.walk_steps; out->levels += w.levels;
         out->idx_hits += w.idx_hits;
+        out->push_tail_ms += w.push_tail_ms; out->push_tail_launches += w.push_tail_launches;
     }
     return FORA_OK;
 }

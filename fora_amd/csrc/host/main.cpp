@@ -244,7 +244,7 @@ static void add_shard_timers(const std::vector<Shard> &shards, int total_slot) {
     double wall = 0, push = 0, walk = 0, other = 0;
     for (auto &s : shards) { // shards run concurrently: the slowest one is the elapsed time
         wall = std::max(wall, s.seconds);
-        push = std::max(push, (s.tm.push_pop_ms + s.tm.push_expand_ms + s.tm.push_accum_ms) * 1e-3);
+        push = std::max(push, (s.tm.push_pop_ms + s.tm.push_expand_ms + s.tm.push_accum_ms + s.tm.push_tail_ms) * 1e-3);
         walk = std::max(walk, (s.tm.walk_alloc_ms + s.tm.walk_ms + s.tm.walk_accum_ms) * 1e-3);
         other = std::max(other, s.tm.other_ms * 1e-3);
     }

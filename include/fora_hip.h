@@ -74,7 +74,7 @@ typedef struct {
 /* Accumulated device timings since the last reset (HIP events on the ctx stream). */
 typedef struct {
     double push_pop_ms;     /* sum over k_push_pop launches (direct path only) */
-    double push_expand_ms;  /* sum over k_pushq_popbin launches (k_push_expand on the direct path) */
+    double push_expand_ms;  /* sum over k_pushq_bin launches (k_push_expand on the direct path) */
     double push_accum_ms;   /* sum over k_accum<false> launches (bucketed push only) */
     double walk_alloc_ms;   /* k_walk_alloc */
     double walk_ms;         /* k_walk_idx + k_walk_online */
@@ -92,6 +92,8 @@ typedef struct {
     uint64_t walk_steps;
     uint64_t levels;        /* levels launched (including speculative empty ones) */
     uint64_t idx_hits;      /* walks served from the index (num_hit_idx, algo.h:39) */
+    double push_tail_ms;    /* k_push_tail launches (they finish the push once every frontier is small) */
+    uint64_t push_tail_launches;
 } fora_timing;
 
 /* ---- lifecycle ---------------------------------------------------------- */
