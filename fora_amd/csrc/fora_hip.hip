@@ -37,7 +37,7 @@ struct Tunables {
     int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
     int64_t tiny = 512;          // k_accum: buckets up to this many messages go by direct atomics
     int64_t xb = 0, ax = 0, wx = 0; // workgroups per slot: bin kernel / slab sweeps / walks (0: from the slot count)
-    int64_t tail = 32768;        // frontier size (largest slot) from which k_push_tail takes over (0: never)
+    int64_t tail = -1;           // frontier size (largest slot) from which k_push_tail takes over (0: never, -1: by slot count)
     int64_t tail_always = 0;     // 1: do not wait for the frontier to have been large first (tests)
     int64_t select_compact = -1; // top-k select over compacted non-zeros: -1 by graph size, 0 never, 1 always
     int64_t rounds = 1;          // threshold rounds of the bucketed push (k_round_sweep): 2^(rounds-1) x the threshold first; 1: plain.
@@ -511,7 +511,11 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, push of 1000 queries (round 2's
     // tail kernel: no agent-scope fences, 4 relaxations in flight per lane): 1024: 86.3 ms, 4096: 85.2, 16384: 82.5,
     // 32768: 81.9, 131072: 163 (one workgroup per slot cannot feed the peak levels)
-    const uint32_t tail_max = (uint32_t)std::max<int64_t>(0, c->opt_.tail);
+    // The tail runs one workgroup per slot, so it only pays while the slots alone fill the chip: with the 14 slots of a
+    // Twitter-2010-sized batch 32768 -> 2048 takes the tail from 128 ms to 11 ms per 28 queries (15.05 -> 15.81 q/s),
+    // with LJ's 140 slots 32768 and 4096 are within 1.5 %.  Default: 32768 scaled by slots / 256, at least 2048.
+    const int64_t tail_auto = std::min<int64_t>(32768, std::max<int64_t>(2048, (int64_t)nq * 128));
+    const uint32_t tail_max = (uint32_t)(c->opt_.tail < 0 ? tail_auto : c->opt_.tail);
     bool past_peak = c->opt_.tail_always == 1; // tests: do not wait for the frontier to have been large first
     for (;; L++) {
         if (level_cap > 0 && L >= level_cap) break; // power iteration: a fixed number of levels
@@ -524,7 +528,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.pass = lo / c->pbins;
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 int h = ev_begin(c, 1);
-                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
+                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), 0, c->stream, dp, L);
                 else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
                 else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 ev_end(c, h);
@@ -663,7 +667,7 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
-                if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
+                if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_HUGE), 0, c->stream, dp);
                 else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
                 hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
             }

@@ -50,6 +50,11 @@ constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B 
 #define FORA_BIN_THREADS_WIDE 512
 #endif
 constexpr int BIN_THREADS_WIDE = FORA_BIN_THREADS_WIDE; // wide bin kernel: 512 threads -> 4096-edge chunks, twice the messages per (chunk, bin) run
+#ifndef FORA_BIN_THREADS_HUGE
+#define FORA_BIN_THREADS_HUGE 1024
+#endif
+constexpr int BIN_THREADS_HUGE = FORA_BIN_THREADS_HUGE; // more than 1024 bins per pass: 8192-edge chunks (Twitter-2010-sized, 28 queries: bin kernel 777 -> 680 ms)
+template <int NB> struct BinThreads { static constexpr int value = NB > 1024 ? BIN_THREADS_HUGE : NB > 128 ? BIN_THREADS_WIDE : 256; };
 constexpr int MAX_SUB = 128; // sub-buckets per (slot, bin) bucket = producer workgroups per slot
 // Narrow layout: a walk result travels as ONE 64-bit word, node id (< 2^20) | weight << 20 (weights are r / num_s_rw,
 // about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
@@ -587,8 +592,8 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // consecutive lanes on consecutive edges through an LDS address table, carrying rowinfo in the frontier entry, and
 // loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
 template <int NB>
-__global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pushq_bin(Dev d, int L) {
-    constexpr int NT = NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
+__global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int L) {
+    constexpr int NT = BinThreads<NB>::value; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
     const int q = blockIdx.y;
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
@@ -699,7 +704,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_pu
             uint32_t staged; // messages of this chunk that belong to the pass's bins
             { // take sub-bucket space (a counter in LDS, no atomic) and lay the bins out in the LDS stage:
               // lane t owns bins t*PER .. t*PER+PER-1
-                constexpr int PER = NB / NT > 0 ? NB / NT : 1;
+                constexpr int PER = (NB + NT - 1) / NT;
                 uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
@@ -1834,8 +1839,8 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
 // go through the same block-level chunk binning as the push (LDS histogram, one global atomic per
 // (chunk, bin), bin-sorted LDS stage, run write-out) and are reduced by k_accum<true>.
 template <int NB>
-__global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_walk_idx(Dev d) {
-    constexpr int NT = NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK; // workgroup size = walk items per tile
+__global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
+    constexpr int NT = BinThreads<NB>::value; // workgroup size = walk items per tile
     constexpr int EPT = BIN_EPT;
     constexpr uint32_t CHUNK = NT * EPT;
     constexpr bool BINNED = NB > 1;
@@ -1921,7 +1926,7 @@ __global__ void __launch_bounds__(NB > MAX_BINS ? BIN_THREADS_WIDE : BLOCK) k_wa
             __syncthreads();
             uint32_t staged; // results of this chunk that belong to the pass's bins
             {
-                constexpr int PER = NB / NT > 0 ? NB / NT : 1;
+                constexpr int PER = (NB + NT - 1) / NT;
                 uint32_t c[PER], mine = 0;
 #pragma unroll
                 for (int j = 0; j < PER; j++) {
