@@ -42,6 +42,7 @@ struct Tunables {
     int64_t select_compact = -1; // top-k select over compacted non-zeros: -1 by graph size, 0 never, 1 always
     int64_t rounds = 1;          // threshold rounds of the bucketed push (k_round_sweep): 2^(rounds-1) x the threshold first; 1: plain.
                                  // 2 rounds relax 17 % fewer edges (ws) but need 99 instead of 61 level launches: push 88 -> 126 ms per 1000 queries
+    int64_t round_div = 4;       // leave a threshold round once the frontier is down to 1/round_div of the round's largest (0: when it is empty)
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -51,7 +52,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 static Tunables tunables_from_env() {
@@ -248,6 +249,9 @@ static bool want_wide(const fora_ctx *c) {
     if (c->opt_.force_wide == 1) return true; // tests: exercise the wide layout on small graphs
     return !((uint64_t)c->n <= (uint64_t)MAX_BINS * BIN_SIZE && (uint64_t)c->n <= (1ull << SEG_BITS));
 }
+// bits of a node id inside its bin: 8192-node bins in the narrow layout, 16384 in the wide ones
+static int bin_shift(const fora_ctx *c) { return want_wide(c) ? BIN_SHIFT_WIDE : BIN_SHIFT; }
+static uint64_t bins_of(const fora_ctx *c) { const int sh = bin_shift(c); return ((uint64_t)c->n + (1ull << sh) - 1) >> sh; }
 static uint32_t want_bk_cap(const fora_ctx *c) {
     if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
     return 163840; // walk results: ~omega*rsum/nbins per bucket (ws: ~110 k)
@@ -256,7 +260,7 @@ static uint32_t want_bk_cap_wide(const fora_ctx *c) { // messages per (slot, bin
     if (c->opt_.bkcap > 0) return (uint32_t)c->opt_.bkcap;
     // a dense level relaxes about every edge once: nnz / nbins messages per bin on average (Twitter-2010-sized: 289 k),
     // hubs' bins beyond that use the overflow list; 196608 covers the indexed walk results (~omega*rsum/nbins per bucket)
-    const uint64_t nbins = ((uint64_t)c->n + BIN_SIZE - 1) >> BIN_SHIFT;
+    const uint64_t nbins = bins_of(c);
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(196608, (uint64_t)(1.4 * (double)c->nnz / (double)std::max<uint64_t>(1, nbins))), 1u << 26);
 }
 
@@ -280,7 +284,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
     if (walks > 4e12) walks = 4e12;
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
-        p.nbins = (int)((n + BIN_SIZE - 1) >> BIN_SHIFT);
+        p.nbins = (int)bins_of(c);
         p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c, p.nbins)) : p.nbins;
         p.sub = want_sub(c, slots);
         { // capacity of one sub-bucket: the bucket's capacity over its sub-buckets (+25 % for uneven producers); the
@@ -326,7 +330,7 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
         uint32_t *sp = split.data() + v * (size_t)(npass + 1);
         sp[0] = 0;
         for (int p = 1; p < npass; p++) {
-            const int64_t first_node = (int64_t)p * pbins * (int64_t)BIN_SIZE;
+            const int64_t first_node = ((int64_t)p * pbins) << bin_shift(c);
             sp[p] = (uint32_t)(std::lower_bound(rb, re, (int32_t)std::min<int64_t>(first_node, INT32_MAX)) - rb);
         }
         sp[npass] = (uint32_t)(re - rb);
@@ -438,6 +442,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.inc_tab[0] = c->d_inc_tab[0]; d.inc_tab[1] = c->d_inc_tab[1]; d.segq_cap = c->segq_cap;
     d.pop_next = 1;
     d.stamps = c->d_stamps;
+    d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
     d.sw_count = c->d_sw; d.sw_done = c->d_sw ? c->d_sw + (size_t)c->B * CSTRIDE : nullptr;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
@@ -533,7 +538,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
-                hipLaunchKernelGGL(k_accum<false>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
+                if (d.wide) hipLaunchKernelGGL((k_accum<false, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L);
+                else hipLaunchKernelGGL((k_accum<false, false>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
                 ev_end(c, h);
             }
             if (d.rounds > 1) { // threshold rounds: slots whose frontier ran dry move on to the next (halved) threshold
@@ -669,14 +675,14 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
                 if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_HUGE), 0, c->stream, dp);
                 else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
-                hipLaunchKernelGGL(k_accum<true>, dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, 0);
+                hipLaunchKernelGGL((k_accum<true, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0);
             }
     }
     hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, c->binned && !d.wide ? wgs : wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
     ev_end(c, h);
     if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets
         h = ev_begin(c, 7);
-        hipLaunchKernelGGL(k_accum<true>, dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
+        hipLaunchKernelGGL((k_accum<true, false>), dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
         ev_end(c, h);
     }
 }
@@ -748,6 +754,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
         rc = push_balanced(c, sources, nq, with_idx);
     } else {
         if (c->binned) d.rounds = (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.rounds, 1), 16);
+        d.round_div = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.round_div, 0), 1 << 20);
         h = ev_begin(c, 4);
         hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 0);
         ev_end(c, h);

@@ -31,15 +31,27 @@ constexpr int MAX_LEVELS = 1 << 15;
 #ifndef FORA_BIN_SHIFT
 #define FORA_BIN_SHIFT 13
 #endif
-constexpr int BIN_SHIFT = FORA_BIN_SHIFT;
+constexpr int BIN_SHIFT = FORA_BIN_SHIFT;      // narrow layout
 constexpr uint32_t BIN_SIZE = 1u << BIN_SHIFT; // 8192 nodes -> 64 KiB of u64 accumulators in LDS
+// Wide layouts: 16384-node bins (128 KiB of accumulators, one 1024-thread accumulate workgroup per CU): half the bins, so
+// twice the messages per (chunk, bin) run, and a Twitter-2010-sized graph (2543 bins) needs ONE bin pass per level instead
+// of two.  Same run: LJ-sized 280 indexed queries 904 -> 833 ms, Twitter-2010-sized 15.96 -> 18.48 q/s.
+#ifndef FORA_BIN_SHIFT_WIDE
+#define FORA_BIN_SHIFT_WIDE 14
+#endif
+constexpr int BIN_SHIFT_WIDE = FORA_BIN_SHIFT_WIDE;
+constexpr uint32_t BIN_SIZE_WIDE = 1u << BIN_SHIFT_WIDE;
 constexpr int MAX_BINS = 128;       // narrow layout: 4-B push messages, staged walk results
-constexpr int MAX_BINS_WIDE = 1024; // wide layout: 8-byte messages (local target | value << 13), up to 1024 bins per pass ...
-constexpr int MAX_BINS_HUGE = 2560; // ... or 2560 for graphs with more bins (Twitter-2010: 5085 bins in 2 passes instead of 5)
+constexpr int MAX_BINS_WIDE = 1024; // wide layout: 8-byte messages (local target | value << 14), up to 1024 bins per pass ...
+constexpr int MAX_BINS_HUGE = 2560; // ... or 2560 for graphs with more bins (Twitter-2010: 2543 bins, one pass)
 #ifndef FORA_ACC_THREADS
 #define FORA_ACC_THREADS 512
 #endif
 constexpr int ACC_THREADS = FORA_ACC_THREADS;
+#ifndef FORA_ACC_THREADS_WIDE
+#define FORA_ACC_THREADS_WIDE 1024
+#endif
+constexpr int ACC_THREADS_WIDE = FORA_ACC_THREADS_WIDE; // 16 nodes per lane in the sweep, as in the narrow layout (512 threads: accumulate 214 -> 265 ms on the LJ-sized graph)
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin / k_walk_idx
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 // bucket messages are read exactly once: non-temporal loads keep them from displacing the increment table and the
@@ -60,10 +72,10 @@ constexpr int MAX_SUB = 128; // sub-buckets per (slot, bin) bucket = producer wo
 // about 2^62 / omega; the rare weight of 2^44 or more goes by a direct atomic).
 constexpr int WPACK_SHIFT = 20;
 constexpr uint64_t WPACK_MAXW = 1ull << (64 - WPACK_SHIFT);
-// Wide layout: every message (push increment or walk result) is ONE 64-bit word, local target (BIN_SHIFT bits) | value <<
-// BIN_SHIFT.  A value of 2^51 or more (the increments of the first one or two levels, about 1e-3 and up) goes through the
+// Wide layout: every message (push increment or walk result) is ONE 64-bit word, local target (BIN_SHIFT_WIDE bits) | value <<
+// BIN_SHIFT_WIDE.  A value of 2^50 or more (the increments of the first one or two levels, about 1e-3 and up) goes through the
 // slot's overflow list (push) or a direct atomic (walk weight) and leaves a null word behind.
-constexpr uint64_t WIDE_MAXV = 1ull << (64 - BIN_SHIFT);
+constexpr uint64_t WIDE_MAXV = 1ull << (64 - BIN_SHIFT_WIDE);
 
 // error flag bits (Dev::err)
 constexpr uint32_t ERR_WL_OVERFLOW = 1, ERR_SEG_OVERFLOW = 2, ERR_WIT_OVERFLOW = 4, ERR_BUCKET_OVERFLOW = 8;
@@ -95,7 +107,7 @@ struct QState {       // per-slot accumulators
     unsigned long long pops, relax;
     unsigned long long n_walks, n_hit, n_rw, ppr_sum;
     uint32_t levels, dangling_source;
-    uint32_t tshift, pad_;       // bucketed push: the slot's current threshold is t1 << tshift (threshold rounds, see k_round_sweep)
+    uint32_t tshift, peak;       // bucketed push: the slot's current threshold is t1 << tshift (threshold rounds, see k_round_sweep); largest frontier of the round so far
 };
 
 struct Dev {
@@ -152,6 +164,7 @@ struct Dev {
     uint64_t *inc_tab[2];
     unsigned long long *stamps; // diagnostic builds (-DFORA_STAMPS): cycles per kernel phase, [0..15] bin kernel, [16..31] accumulate
     int32_t rounds;         // threshold rounds of the bucketed push (k_round_sweep); 1: the plain schedule
+    uint32_t round_div;     // a round is left once its frontier is down to 1/round_div of its largest one (0: only when empty)
     uint32_t *sw_count, *sw_done; // [slot * CSTRIDE] k_round_sweep: entries appended / workgroups finished (both return to 0)
     int32_t pop_next;       // k_accum<false>: pop the crossing nodes for the next level (0 on the last level of a capped run)
     uint64_t segq_cap;      // = n: a frontier holds each node at most once
@@ -602,11 +615,14 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
         if (count) d.qs[q].levels++;          // levels in which the slot popped (this thread is the only writer in a launch)
+        if (d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
     }
     if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
+    constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
+    constexpr uint32_t BSZ = 1u << BS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
-    static_assert(BIN_SHIFT + SRC_BITS <= 32, "wide stage word: local target | source entry");
+    static_assert(BS + SRC_BITS <= 32, "wide stage word: local target | source entry");
     constexpr uint32_t CHUNK = NT * BIN_EPT;
     __shared__ int64_t s_ebeg[NT];
     __shared__ uint64_t s_inc[NT];
@@ -696,8 +712,8 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
-                if (w[k] != 0xFFFFFFFFu && (w[k] >> BIN_SHIFT) - bin_lo >= bin_cnt) w[k] = 0xFFFFFFFFu; // another pass's bins
-                if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(w[k] >> BIN_SHIFT) - bin_lo], 1u); // rank inside (chunk, bin)
+                if (w[k] != 0xFFFFFFFFu && (w[k] >> BS) - bin_lo >= bin_cnt) w[k] = 0xFFFFFFFFu; // another pass's bins
+                if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(w[k] >> BS) - bin_lo], 1u); // rank inside (chunk, bin)
             }
             __syncthreads();
             STAMP(1);
@@ -734,10 +750,10 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
                 if (w[k] != 0xFFFFFFFFu) {
-                    const uint32_t b = (w[k] >> BIN_SHIFT) - bin_lo;
+                    const uint32_t b = (w[k] >> BS) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
                     const uint32_t own = si[k];
-                    s_msg[sp] = WIDE ? (w[k] & (BIN_SIZE - 1)) | (own << BIN_SHIFT) : ((w[k] & (BIN_SIZE - 1)) << SEG_BITS) | (tbase + own);
+                    s_msg[sp] = WIDE ? (w[k] & (BSZ - 1)) | (own << BS) : ((w[k] & (BSZ - 1)) << SEG_BITS) | (tbase + own);
                     s_bin[sp] = b;
                 }
             }
@@ -747,7 +763,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                 const uint32_t e = s_msg[m];
                 const uint32_t b = s_bin[m];
                 uint32_t sidx, local;
-                if (WIDE) { sidx = e >> BIN_SHIFT; local = e & (BIN_SIZE - 1); }
+                if (WIDE) { sidx = e >> BS; local = e & (BSZ - 1); }
                 else { sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
                 const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk: its messages end at s_fill[b]
                 const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
@@ -756,13 +772,13 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     if (WIDE) {
                         const uint64_t inc = s_inc[sidx];
                         parked = inc >= WIDE_MAXV; // does not fit the packed word: null word here, the increment goes to the list
-                        d.bk_inc[at] = parked ? 0ull : (uint64_t)local | (inc << BIN_SHIFT);
+                        d.bk_inc[at] = parked ? 0ull : (uint64_t)local | (inc << BS);
                     } else d.bk_w[at] = e;
                 }
                 if (parked) { // park the increment in the slot's overflow list, folded in by k_accum
                     const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
                     if (oi < d.ov_cap) {
-                        d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BIN_SHIFT) | local;
+                        d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BS) | local;
                         d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
                         atomicAdd(&d.ov_bin[par][(uint64_t)q * d.nbins + bin_lo + b], 1u);
                     } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
@@ -947,7 +963,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
     if (tid == 0 && levels_run) d.qs[q].levels += levels_run;
 }
 
-// grid = (bins of the pass, nq), ACC_THREADS threads.  TO_PPR: the buckets hold walk results; they are added
+// grid = (bins of the pass, nq), ACC_THREADS (wide layouts: ACC_THREADS_WIDE) threads.  TO_PPR: the buckets hold walk results; they are added
 // to the ppr slab and there is no threshold / frontier.
 //
 // Push form (TO_PPR = false), level L: after the sweep has added the level's increments to the residue range this
@@ -955,11 +971,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
 // (d.pop_next = 0 on the last level of a capped run leaves it alone): its residue is in registers, so the slab word is
 // stored as 0 (algo.h:984-985) and (node, residue) is appended at a rank that follows the NODE ORDER inside the bin.
 // The bin kernel of the next level finishes the pop with dense lanes and never gathers a residue.
-template <bool TO_PPR>
-__global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
-    __shared__ uint64_t acc[BIN_SIZE];
-    constexpr int NW = ACC_THREADS / 64;
-    constexpr int SWEEP = BIN_SIZE / ACC_THREADS;
+template <bool TO_PPR, bool WIDE>
+__global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum(Dev d, int L) {
+    constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target
+    constexpr uint32_t BSZ = 1u << BS;
+    constexpr int AT = WIDE ? ACC_THREADS_WIDE : ACC_THREADS;
+    __shared__ uint64_t acc[BSZ];
+    constexpr int NW = AT / 64;
+    constexpr int SWEEP = BSZ / AT;
+    static_assert(SWEEP <= 32, "crossmask holds one bit per swept node of a lane");
     __shared__ uint32_t s_rank[SWEEP * NW + 1];
     __shared__ uint32_t s_gbase;
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
@@ -995,7 +1015,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         }
     }
     const uint32_t s = (uint32_t)d.src[q];
-    const uint64_t dm = (!TO_PPR && (int)(s >> BIN_SHIFT) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
+    const uint64_t dm = (!TO_PPR && (int)(s >> BS) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
     uint64_t *target = TO_PPR ? d.ppr : d.residue;
     __syncthreads();
     const uint32_t cnt = s_total;
@@ -1006,15 +1026,15 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
     uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
     uint32_t *flc_next = &d.fl_count[par ^ 1][q * CSTRIDE];
     const uint64_t bk0 = bi * sub * d.bk_cap; // sub-bucket x starts at bk0 + x * bk_cap
-    const uint32_t node0 = (uint32_t)b << BIN_SHIFT;
+    const uint32_t node0 = (uint32_t)b << BS;
     const uint64_t *itab = TO_PPR ? nullptr : d.inc_tab[par] + (uint64_t)q * d.segq_cap;
     const uint64_t t1q = TO_PPR ? 0 : thr_unit(d.t1, d.qs[q].tshift); // the slot's threshold unit in its current round
     // message forms: narrow push = 4-byte word (local target << SEG_BITS | frontier position), increment gathered from the
     // table; everything else = ONE 64-bit word in bk_inc: narrow walk results node id | weight << WPACK_SHIFT, wide
-    // messages local target | value << BIN_SHIFT
-    const bool gather = !TO_PPR && !d.wide;
+    // messages local target | value << BS
+    const bool gather = !TO_PPR && !WIDE;
     const bool packed = !gather;
-    const int pshift = d.wide ? BIN_SHIFT : WPACK_SHIFT;
+    const int pshift = WIDE ? BS : WPACK_SHIFT;
     if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
         // node range and the level's pops are done, so nothing else touches these words).  Wave w takes sub-buckets
@@ -1031,7 +1051,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                     if (packed) {
                         const uint64_t pk = d.bk_inc[at0 + i];
                         w = (uint32_t)pk & ((1u << pshift) - 1);
-                        if (d.wide) w += node0;
+                        if (WIDE) w += node0;
                         inc = pk >> pshift;
                     } else {
                         w = d.bk_w[at0 + i];
@@ -1063,7 +1083,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         if (!nl) return;
         if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, nl);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nl; i += ACC_THREADS) {
+        for (uint32_t i = threadIdx.x; i < nl; i += AT) {
             const uint32_t w = s_list[i];
             const uint64_t r = atomicExch((unsigned long long *)&d.residue[slab + w], 0ull); // algo.h:984-985
             const uint32_t pos = s_gbase + i;
@@ -1073,7 +1093,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         return;
     } else {
     STAMP_DECL
-    for (uint32_t i = threadIdx.x; i < BIN_SIZE; i += ACC_THREADS) acc[i] = 0;
+    for (uint32_t i = threadIdx.x; i < BSZ; i += AT) acc[i] = 0;
     __syncthreads();
     STAMP(16);
     // messages: wave w takes sub-buckets w, w + NW, ...; ACC_UNROLL x 64 messages per iteration, all loads BRANCH-FREE
@@ -1104,15 +1124,15 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                 uint32_t local = mw[k] >> SEG_BITS;
                 uint64_t inc = mi[k];
                 if (packed) { local = (uint32_t)inc; inc >>= pshift; }
-                if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BIN_SIZE - 1)], (unsigned long long)inc);
+                if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BSZ - 1)], (unsigned long long)inc);
             }
         }
     }
-    if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BIN_SIZE - 1)], (unsigned long long)dm);
-    for (uint32_t i = threadIdx.x; i < ovn; i += ACC_THREADS) { // increments whose bucket was full
+    if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BSZ - 1)], (unsigned long long)dm);
+    for (uint32_t i = threadIdx.x; i < ovn; i += AT) { // increments whose bucket was full
         const uint32_t w = d.ov_w[(uint64_t)q * d.ov_cap + i];
-        if ((int)(w >> BIN_SHIFT) == b)
-            atomicAdd((unsigned long long *)&acc[w & (BIN_SIZE - 1)], (unsigned long long)d.ov_inc[(uint64_t)q * d.ov_cap + i]);
+        if ((int)(w >> BS) == b)
+            atomicAdd((unsigned long long *)&acc[w & (BSZ - 1)], (unsigned long long)d.ov_inc[(uint64_t)q * d.ov_cap + i]);
     }
     __syncthreads();
     STAMP(17);
@@ -1122,12 +1142,12 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         uint64_t v[SWEEP], old[SWEEP];
         uint32_t dg[SWEEP];
 #pragma unroll
-        for (int k = 0; k < SWEEP; k++) v[k] = acc[k * ACC_THREADS + threadIdx.x];
+        for (int k = 0; k < SWEEP; k++) v[k] = acc[k * AT + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
             old[k] = 0; dg[k] = 0;
             if (v[k]) {
-                const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+                const uint32_t node = node0 + k * AT + threadIdx.x;
                 old[k] = target[slab + node];
                 if (!TO_PPR) dg[k] = d.deg[node];
             }
@@ -1135,7 +1155,7 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         const bool pop = !TO_PPR && d.pop_next;
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
-            const uint32_t node = node0 + k * ACC_THREADS + threadIdx.x;
+            const uint32_t node = node0 + k * AT + threadIdx.x;
             if (v[k]) {
                 const uint64_t nw = old[k] + v[k];
                 bool cross = false;
@@ -1143,30 +1163,32 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
                     const uint64_t thr = node_thr(t1q, dg[k]);
                     cross = pop && old[k] < thr && nw >= thr; // algo.h:1012
                 }
-                // this workgroup owns [node0, node0 + BIN_SIZE) of slot q; a crossing node gives its residue to the
+                // this workgroup owns [node0, node0 + BSZ) of slot q; a crossing node gives its residue to the
                 // frontier entry written below (algo.h:984-985)
                 target[slab + node] = cross ? 0 : nw;
-                if (cross) { crossmask |= 1u << k; acc[k * ACC_THREADS + threadIdx.x] = nw; } // own LDS word: no barrier needed
+                if (cross) { crossmask |= 1u << k; acc[k * AT + threadIdx.x] = nw; } // own LDS word: no barrier needed
             }
         }
     }
     STAMP(18);
     if (TO_PPR) { STAMP_FLUSH(16); return; }
-    // ---- rank of every crossing node in node order: node = node0 + k * ACC_THREADS + thread, so order by (k, wave, lane)
+    // ---- rank of every crossing node in node order: node = node0 + k * AT + thread, so order by (k, wave, lane)
     constexpr int CELLS = SWEEP * NW;
-    static_assert(CELLS <= 128, "the scan below handles two (k, wave) cells per lane of one wave");
+    constexpr int CPL = (CELLS + 63) / 64; // cells per lane of the one wave that scans them
 #pragma unroll
     for (int k = 0; k < SWEEP; k++) {
         const unsigned long long m = __ballot((crossmask >> k) & 1u);
         if (lane == 0) s_rank[k * NW + wid] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    if (wid == 0) { // exclusive scan of the (k, wave) counts by one wave, two per lane
-        const uint32_t c0 = 2 * lane < CELLS ? s_rank[2 * lane] : 0, c1 = 2 * lane + 1 < CELLS ? s_rank[2 * lane + 1] : 0;
+    if (wid == 0) { // exclusive scan of the (k, wave) counts by one wave, CPL consecutive cells per lane
+        uint32_t cc[CPL], sum = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; j++) { cc[j] = CPL * lane + j < CELLS ? s_rank[CPL * lane + j] : 0; sum += cc[j]; }
         uint32_t tot;
-        const uint32_t ex = wave_excl_scan(c0 + c1, tot);
-        if (2 * lane < CELLS) s_rank[2 * lane] = ex;
-        if (2 * lane + 1 < CELLS) s_rank[2 * lane + 1] = ex + c0;
+        uint32_t ex = wave_excl_scan(sum, tot);
+#pragma unroll
+        for (int j = 0; j < CPL; j++) { if (CPL * lane + j < CELLS) s_rank[CPL * lane + j] = ex; ex += cc[j]; }
         if (lane == 0) {
             s_rank[CELLS] = tot;
             s_gbase = tot ? atomicAdd(flc_next, tot) : 0u; // ONE global atomic per workgroup (the per-slot counter is a hot address)
@@ -1183,8 +1205,8 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
         if (c) {
             const uint32_t pos = gbase + s_rank[k * NW + wid] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
             if (pos < (uint32_t)d.n) {
-                fl_next[pos] = node0 + k * ACC_THREADS + threadIdx.x;
-                inc_next[pos] = acc[k * ACC_THREADS + threadIdx.x];
+                fl_next[pos] = node0 + k * AT + threadIdx.x;
+                inc_next[pos] = acc[k * AT + threadIdx.x];
             } else atomicOr(d.err, ERR_WL_OVERFLOW);
         }
     }
@@ -1196,9 +1218,10 @@ __global__ void __launch_bounds__(ACC_THREADS) k_accum(Dev d, int L) {
 // ---- threshold rounds.  A level-synchronous push pops a node the level after it crosses its threshold, with whatever
 // it has collected by then; the FIFO of algo.h:980-1017 lets it collect more before its turn, so it moves more mass
 // per relaxed edge.  Rounds give that back: a slot first runs its levels against 2^(rounds-1) times the threshold
-// (every pop there carries at least that much more per edge); when its frontier runs dry, this kernel halves the
-// threshold and sweeps the slot's residue slab once for every node at or over the new one -- they become the next
-// frontier, as (node, residue) entries like k_accum's.  Two rounds (2x, then 1x) cut the relaxations of the ws-sized
+// (every pop there carries at least that much more per edge); when its frontier runs dry -- or, with round_div > 0,
+// is down to 1/round_div of the round's largest frontier, so that the round's long tail of small levels is not run
+// twice -- this kernel halves the threshold and sweeps the slot's residue slab once for every node at or over the
+// new one: they join the next frontier, as (node, residue) entries like k_accum's.  Two rounds (2x, then 1x) cut the relaxations of the ws-sized
 // headline graph from 1.27x to 1.05x of the sequential FIFO's.  Exit condition and invariants are those of algo.h:1012.
 // grid = (X, nq), after the accumulate of level L.  Every workgroup of a slot takes the same decision: nothing below
 // touches the frontier count before the slot's LAST workgroup is done.
@@ -1207,7 +1230,11 @@ __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
     const int np = (L & 1) ^ 1;
     QState *qs = &d.qs[q];
     const uint32_t ts = qs->tshift;
-    if (ts == 0 || d.fl_count[np][q * CSTRIDE] != 0) return; // last round, or the slot still has a frontier
+    if (ts == 0) return; // last round
+    // the frontier the accumulate has just written: entries whose residue is already taken, the sweep appends to them.
+    // Every workgroup of the slot reads the same (count, peak, shift): only the last one to finish changes them.
+    const uint32_t have = d.fl_count[np][q * CSTRIDE];
+    if (have != 0 && !(d.round_div > 0 && (uint64_t)have * d.round_div <= qs->peak)) return; // the round goes on
     const int lane = threadIdx.x & 63;
     const uint64_t unit = thr_unit(d.t1, ts - 1);
     const uint64_t slab = (uint64_t)q * d.n;
@@ -1227,7 +1254,7 @@ __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
         base = __shfl(base, 0);
         if (in) {
             d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
-            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            const uint32_t pos = have + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
             if (pos < (uint32_t)d.n) { d.fl[np][slab + pos] = v; d.inc_tab[np][(uint64_t)q * d.segq_cap + pos] = r; }
             else atomicOr(d.err, ERR_WL_OVERFLOW);
         }
@@ -1239,8 +1266,9 @@ __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
         if (ticket == gridDim.x - 1) { // the slot's last workgroup publishes the new frontier and the new round
             __threadfence();
             const uint32_t cnt = atomicExch(&d.sw_count[q * CSTRIDE], 0u);
-            d.fl_count[np][q * CSTRIDE] = cnt;
+            d.fl_count[np][q * CSTRIDE] = min(have + cnt, (uint32_t)d.n);
             qs->tshift = ts - 1;
+            qs->peak = 0;
             d.fl_count[0][q * CSTRIDE + 1] = ts - 1;
             d.fl_count[1][q * CSTRIDE + 1] = ts - 1;
             atomicExch(&d.sw_done[q * CSTRIDE], 0u);
@@ -1845,8 +1873,10 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     constexpr uint32_t CHUNK = NT * EPT;
     constexpr bool BINNED = NB > 1;
     constexpr bool WIDE = NB > MAX_BINS;
+    constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
+    constexpr uint32_t BSZ = 1u << BS;
     constexpr int IB = NT == 256 ? 8 : NT == 512 ? 9 : 10; // bits of an item index inside the tile
-    constexpr int DB = WIDE ? BIN_SHIFT : WPACK_SHIFT;     // bits of the destination in a stage word: local target / node id
+    constexpr int DB = WIDE ? BS : WPACK_SHIFT;     // bits of the destination in a stage word: local target / node id
     static_assert(DB + IB + 1 <= 32, "stage word: destination | item | carries-one-more-unit");
     __shared__ uint64_t s_j0[NT], s_pos[NT], s_incr[NT], s_rem[NT];
     __shared__ uint32_t s_pref[NT + 1], s_w[NT / 64];
@@ -1920,8 +1950,8 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
             }
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
-                if (dest[k] != 0xFFFFFFFFu && (dest[k] >> BIN_SHIFT) - bin_lo >= bin_cnt) dest[k] = 0xFFFFFFFFu; // another pass
-                if (dest[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(dest[k] >> BIN_SHIFT) - bin_lo], 1u);
+                if (dest[k] != 0xFFFFFFFFu && (dest[k] >> BS) - bin_lo >= bin_cnt) dest[k] = 0xFFFFFFFFu; // another pass
+                if (dest[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(dest[k] >> BS) - bin_lo], 1u);
             }
             __syncthreads();
             uint32_t staged; // results of this chunk that belong to the pass's bins
@@ -1955,9 +1985,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
 #pragma unroll
             for (int k = 0; k < EPT; k++) {
                 if (dest[k] != 0xFFFFFFFFu) {
-                    const uint32_t b = (dest[k] >> BIN_SHIFT) - bin_lo;
+                    const uint32_t b = (dest[k] >> BS) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
-                    s_msg[sp] = (WIDE ? dest[k] & (BIN_SIZE - 1) : dest[k]) | (li[k] << DB);
+                    s_msg[sp] = (WIDE ? dest[k] & (BSZ - 1) : dest[k]) | (li[k] << DB);
                     s_bin[sp] = (uint16_t)b;
                 }
             }
@@ -1970,7 +2000,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
                 const bool fits = wgt < (WIDE ? WIDE_MAXV : WPACK_MAXW);
                 if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * sub * d.bk_cap + pos] = fits ? (uint64_t)dd | (wgt << DB) : 0ull;
                 if (pos >= d.bk_cap || !fits) // sub-bucket full / weight too large for the packed word: direct atomic, same sum
-                    atomicAdd((unsigned long long *)&d.ppr[slab + (WIDE ? ((bin_lo + b) << BIN_SHIFT) | dd : dd)], (unsigned long long)wgt);
+                    atomicAdd((unsigned long long *)&d.ppr[slab + (WIDE ? ((bin_lo + b) << BS) | dd : dd)], (unsigned long long)wgt);
             }
         }
         __syncthreads();

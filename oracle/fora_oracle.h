@@ -135,6 +135,8 @@ typedef struct {
 /* threshold rounds of orc_twin_push / orc_twin_query (the engine's option "rounds"; default 1) */
 void orc_twin_set_rounds(int rounds);
 int orc_twin_get_rounds(void);
+void orc_twin_set_round_div(int div); /* 0 (default): a round ends when its frontier is empty */
+int orc_twin_get_round_div(void);
 int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
                   double alpha, uint64_t *residue, uint64_t *ppr, orc_twin_push_stats *st,
                   int64_t *level_sizes, int64_t cap);

@@ -52,12 +52,17 @@ void orc_fix_to_double(const uint64_t *in, int64_t n, double *out) {
     for (int64_t i = 0; i < n; i++) out[i] = fix2d(in[i]);
 }
 
-/* Runs levels until the frontier is empty.  frontier holds *fn nodes on entry. */
-static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, uint64_t t1,
-                        uint64_t afix, uint64_t *residue, uint64_t *reserve, int32_t *frontier,
-                        int64_t fn, int32_t *next, uint64_t *inc, orc_twin_push_stats *st,
-                        int64_t *level_sizes, int64_t cap, int64_t max_levels) {
+/* Runs levels until the frontier is empty.  frontier holds fn nodes on entry.  With switch_div > 0 (threshold
+ * rounds) it also stops before a level whose frontier has shrunk to 1/switch_div of the largest one of this call;
+ * the nodes of that frontier are still unpopped (they keep their residue).  Returns the size of the frontier left. */
+static int64_t twin_levels_div(const int64_t *row_ptr, const int32_t *col, int32_t s, uint64_t t1,
+                               uint64_t afix, uint64_t *residue, uint64_t *reserve, int32_t *frontier,
+                               int64_t fn, int32_t *next, uint64_t *inc, orc_twin_push_stats *st,
+                               int64_t *level_sizes, int64_t cap, int64_t max_levels, int64_t switch_div) {
+    int64_t peak = 0;
     while (fn > 0 && (max_levels <= 0 || st->levels < max_levels)) {
+        if (switch_div > 0 && fn * switch_div <= peak) return fn;
+        if (fn > peak) peak = fn;
         if (level_sizes && st->levels < cap) level_sizes[st->levels] = fn;
         st->levels++;
         uint64_t dang = 0;
@@ -103,15 +108,28 @@ static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, u
         memcpy(frontier, next, sizeof(int32_t) * (size_t)nn);
         fn = nn;
     }
+    return fn;
+}
+
+static void twin_levels(const int64_t *row_ptr, const int32_t *col, int32_t s, uint64_t t1,
+                        uint64_t afix, uint64_t *residue, uint64_t *reserve, int32_t *frontier,
+                        int64_t fn, int32_t *next, uint64_t *inc, orc_twin_push_stats *st,
+                        int64_t *level_sizes, int64_t cap, int64_t max_levels) {
+    (void)twin_levels_div(row_ptr, col, s, t1, afix, residue, reserve, frontier, fn, next, inc, st, level_sizes, cap,
+                          max_levels, 0);
 }
 
 /* Threshold rounds of the HIP push (fora_kernels.h k_round_sweep): the levels first run against 2^(rounds-1) times the
- * threshold; whenever the frontier runs dry the threshold is halved and every node at or over the new one (found by
- * a sweep over the residues) forms the next frontier, down to the threshold of algo.h:1012 itself.  rounds = 1 is the
- * plain level-synchronous schedule and the engine's default (option "rounds"). */
+ * threshold; whenever the frontier runs dry -- or, with round_div > 0, has shrunk to 1/round_div of the round's
+ * largest frontier -- the threshold is halved and every node at or over the new one (found by a sweep over the
+ * residues; this includes the nodes of the frontier that was left) forms the next frontier, down to the threshold of
+ * algo.h:1012 itself.  rounds = 1 is the plain level-synchronous schedule (option "rounds" / "round_div"). */
 static int g_twin_rounds = 1;
+static int g_twin_round_div = 0;
 void orc_twin_set_rounds(int rounds) { g_twin_rounds = rounds < 1 ? 1 : rounds > 16 ? 16 : rounds; }
 int orc_twin_get_rounds(void) { return g_twin_rounds; }
+void orc_twin_set_round_div(int div) { g_twin_round_div = div < 0 ? 0 : div; }
+int orc_twin_get_round_div(void) { return g_twin_round_div; }
 static uint64_t thr_unit(uint64_t t1, int k) { return k == 0 ? t1 : ((t1 >> (63 - k)) ? (UINT64_MAX >> 1) : (t1 << k)); }
 
 /* Twin of forward_local_update_linear (algo.h:954-1018). */
@@ -142,7 +160,9 @@ int orc_twin_push(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t
                 for (int32_t v = 0; v < n; v++)
                     if (residue[v] && residue[v] >= node_thr(unit, row_ptr[v + 1] - row_ptr[v])) frontier[fn++] = v;
             }
-            twin_levels(row_ptr, col, s, unit, afix, residue, ppr, frontier, fn, next, inc, &z, level_sizes, cap, 0);
+            /* the last round runs dry; earlier ones may be left early (their pending nodes are found again by the sweep) */
+            (void)twin_levels_div(row_ptr, col, s, unit, afix, residue, ppr, frontier, fn, next, inc, &z, level_sizes, cap, 0,
+                                  k > 0 ? g_twin_round_div : 0);
         }
     }
     uint64_t reserved = 0;

@@ -278,6 +278,11 @@ def twin_set_rounds(rounds):
     lib().orc_twin_set_rounds(C.c_int(int(rounds)))
 
 
+def twin_set_round_div(div):
+    """Leave a threshold round once the frontier is down to 1/div of the round's largest (0: only when it is empty)."""
+    lib().orc_twin_set_round_div(C.c_int(int(div)))
+
+
 def twin_query(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None):
     residue = np.zeros(g.n, dtype=np.uint64)
     ppr = np.zeros(g.n, dtype=np.uint64)

@@ -111,6 +111,31 @@ def test_query_bit_exact_vs_twin(engine, oracle, request, gname, opt):
 
 
 @pytest.mark.parametrize("opt", [False, True])
+@pytest.mark.parametrize("copy", ["compact", "csr"])
+def test_walk_graph_copies_agree(engine, oracle, small_dangling, copy, opt):
+    """The online walk kernel steps through the bit-packed compact copy of the graph (the default below 2^31 edges) or
+    the plain CSR, chosen at set_graph.  Same edge choice in both: queries and the index build equal the twin bit for
+    bit."""
+    g = small_dangling
+    engine.set_option("no_compact", 1 if copy == "csr" else 0)
+    try:
+        rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
+        srcs = np.concatenate([pick_sources(g, 3, 25), pick_sources(g, 1, 26, want_dangling=True)])
+        ppr, _, st = engine.query_fix(srcs, want_residue=False)
+        for i, s in enumerate(srcs):
+            want, _, wst = oracle.twin_query(g, int(s), rmax, omega, opt=opt, seed=SEED)
+            assert (ppr[i] == want).all() and st[i]["n_walks"] == wst["n_walks"]
+        engine.build_index()
+        rw, _, _ = engine.get_index()
+        want_rw, _, _ = oracle.build_index(g, SEED, rmax, omega, opt=opt)
+        assert (rw == want_rw).all()
+    finally:
+        engine.reset_options()
+        engine.clear_index()
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+
+
+@pytest.mark.parametrize("opt", [False, True])
 def test_index_build_and_indexed_query_bit_exact(engine, oracle, small, opt):
     g = small
     rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
@@ -354,19 +379,21 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
-@pytest.mark.parametrize("rounds", [1, 2, 3, 5])
-def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds):
-    """Threshold rounds of the push (k_round_sweep; option "rounds", default 1 = off): 2^(rounds-1) x the threshold
-    first, halved whenever a slot's frontier runs dry.  Every setting equals the twin running the same schedule bit for
-    bit, ends with the exit condition of algo.h:1012, and more rounds never relax more edges than the plain schedule
-    (they need more, smaller levels though, which is why the default stays at 1: DESIGN.md 5.4)."""
+@pytest.mark.parametrize("rounds,div", [(1, 0), (2, 0), (3, 0), (5, 0), (2, 4), (2, 2), (3, 4), (4, 1), (3, 1000000)])
+def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds, div):
+    """Threshold rounds of the push (k_round_sweep; options "rounds" and "round_div"): 2^(rounds-1) x the threshold
+    first, halved whenever a slot's frontier runs dry (div = 0) or is down to 1/div of the round's largest frontier.
+    Every setting equals the twin running the same schedule bit for bit and ends with the exit condition of
+    algo.h:1012; rounds that run dry never relax more edges than the plain schedule."""
     g = small_dangling
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = np.concatenate([pick_sources(g, 6, 71), pick_sources(g, 1, 72, want_dangling=True)])
     engine.set_option("rounds", 1)
     _, _, st1 = engine.push(srcs)
     engine.set_option("rounds", rounds)
+    engine.set_option("round_div", div)
     oracle.twin_set_rounds(rounds)
+    oracle.twin_set_round_div(div)
     try:
         rsv, res, st = engine.push(srcs)
         t1 = int(np.ceil(np.ldexp(rmax, 62)))
@@ -378,7 +405,8 @@ def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds):
             thr = (t1 * g.deg).astype(np.uint64)
             thr[g.deg == 0] = 1
             assert (res[i] < thr).all()
-        assert sum(int(x["relax"]) for x in st) <= sum(int(x["relax"]) for x in st1)
+        if div == 0:
+            assert sum(int(x["relax"]) for x in st) <= sum(int(x["relax"]) for x in st1)
         ppr, _, stq = engine.query_fix(srcs[:3], want_residue=False)
         for i in range(3):
             want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
@@ -386,6 +414,7 @@ def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds):
     finally:
         engine.reset_options()
         oracle.twin_set_rounds(1)
+        oracle.twin_set_round_div(0)
 
 
 def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
