@@ -126,6 +126,7 @@ struct fora_ctx {
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
     uint8_t *d_active = nullptr;
     unsigned long long *d_above = nullptr;
+    double *d_sel_thr = nullptr; // [B] launch_select: per-slot limit of the entries that can be among the top k
     // top-k with bounds: upper_bounds / lower_bounds (query.h:1350-1353), topk_filter marks, stop flags, walks of the round
     double *d_upper = nullptr, *d_lower = nullptr;
     uint8_t *d_filter = nullptr;
@@ -195,7 +196,7 @@ void free_index(fora_ctx *c) {
 void free_workspace(fora_ctx *c) {
     dfree(c->d_residue); dfree(c->d_ppr); dfree(c->d_wl[0]); dfree(c->d_wl[1]); dfree(c->d_scratch);
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
-    dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+    dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_sel_thr); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     dfree(c->d_upper); dfree(c->d_lower); dfree(c->d_filter); dfree(c->d_fail); dfree(c->d_round_walks);
     dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
     dfree(c->d_nz_counts);
@@ -272,7 +273,8 @@ static uint32_t want_sub(const fora_ctx *c, int slots) {
     // wide: 512-thread producers, 2-3 resident per CU.  LJ-sized, 74 slots: 16 -> 549 ms per 148 queries, 32 -> 492, 64 -> 515,
     // 128 -> 539; Twitter-sized, 12 slots, 24 queries: 32 -> 2438 ms, 64 -> 2010, 128 -> 1576 (few slots: the tiles of a level
     // have to be dealt to many workgroups)
-    if (want_wide(c)) return slots >= 32 ? 32u : (uint32_t)MAX_SUB;
+    // (16384-node bins, LJ-sized, 140 slots, 280 queries: 16 -> 902 ms, 32 -> 840, 64 -> 826)
+    if (want_wide(c)) return slots >= 256 ? 32u : slots >= 32 ? 64u : (uint32_t)MAX_SUB;
     return (uint32_t)std::min(MAX_SUB, std::max(16, 16384 / std::max(1, slots)));
 }
 static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
@@ -606,7 +608,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
 // k_topk_select over the slabs of `ds.ppr`; large graphs first compact each slot's non-zero entries (in id order, so
 // ties keep resolving to the lowest ids) into the push's frontier / increment buffers, which are idle here.
 constexpr unsigned NZ_X = 1024;
-int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, double *scores, int raw) {
+int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, double *scores, int raw, const double *h_thr = nullptr) {
     bool compact = c->binned && c->n >= (1 << 20);
     if (c->opt_.select_compact >= 0) compact = c->binned && c->opt_.select_compact == 1; // tests: force / forbid the compacted form
     if (!compact) {
@@ -618,9 +620,16 @@ int launch_select(fora_ctx *c, const Dev &ds, int nb, int k, int32_t *ids, doubl
     const unsigned X = (unsigned)std::min<uint64_t>(NZ_X, ((uint64_t)c->n + 4095) / 4096);
     const uint32_t R = (uint32_t)(((uint64_t)c->n + X - 1) / X);
     uint32_t *ccount = c->d_nz_counts + (size_t)c->B * NZ_X;
-    hipLaunchKernelGGL(k_nz_count, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, c->d_nz_counts);
+    const double *thr = nullptr; // per-slot lower limit of the entries worth compacting (see k_nz_count)
+    if (h_thr && !raw) {
+        if (!c->d_sel_thr) HIPCHK(c, hipMalloc(&c->d_sel_thr, (size_t)c->B * sizeof(double)));
+        HIPCHK(c, hipMemcpyAsync(c->d_sel_thr, h_thr, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // h_thr is the caller's pageable buffer
+        thr = c->d_sel_thr;
+    }
+    hipLaunchKernelGGL(k_nz_count, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, c->d_nz_counts, thr);
     hipLaunchKernelGGL(k_nz_write, dim3(X, nb), dim3(BLOCK), 0, c->stream, ds, R, (const uint32_t *)c->d_nz_counts, c->d_fl[0],
-                       c->d_inc_tab[0], ccount);
+                       c->d_inc_tab[0], ccount, thr);
     hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(SEL_THREADS), 0, c->stream, ds, k, ids, scores, raw,
                        (const uint32_t *)c->d_fl[0], (const uint64_t *)c->d_inc_tab[0], (const uint32_t *)ccount);
     return FORA_OK;
@@ -1389,6 +1398,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
         for (int i = 0; i < nb; i++) // dangling source: query.h:1007-1011, one round, ppr = e_s
             if (c->h_row_ptr[sources[b0 + i] + 1] == c->h_row_ptr[sources[b0 + i]]) active[i] = 0;
         std::vector<int32_t> nround((size_t)nb, 1);
+        std::vector<double> sel_thr((size_t)nb, 0.0); // slots that stop with k entries >= T: the top k are among those
         // ppr2 := reserve for every slot once (covers dangling sources)
         hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
                            (const uint8_t *)nullptr);
@@ -1430,7 +1440,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, with_idx ? 1 : 0);
             const double T = (1 + epsilon) * delta; // query.h:1030
             h = ev_begin(c, 4);
-            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,
+            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 256), nb), dim3(BLOCK), 0, c->stream, dw,
                                (const uint8_t *)c->d_active, T, c->d_above);
             ev_end(c, h);
             above.assign((size_t)nb, 0);
@@ -1438,7 +1448,10 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             rc = check_dev_err(c);
             if (rc) return rc;
             for (int i = 0; i < nb; i++)
-                if (active[i] && (above[i] >= (unsigned long long)k || delta <= min_delta)) active[i] = 0;
+                if (active[i] && (above[i] >= (unsigned long long)k || delta <= min_delta)) {
+                    active[i] = 0;
+                    if (above[i] >= (unsigned long long)k) sel_thr[i] = T;
+                }
             if (delta <= min_delta) break;
             delta = std::max(min_delta, delta / 4.0); // query.h:1041
         }
@@ -1446,7 +1459,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
         Dev ds = make_dev(c, nb, false);
         ds.ppr = c->d_ppr2;
         int h = ev_begin(c, 4);
-        rc = launch_select(c, ds, nb, k, c->d_topk_ids, c->d_topk_sc, 0);
+        rc = launch_select(c, ds, nb, k, c->d_topk_ids, c->d_topk_sc, 0, sel_thr.data());
         if (rc) return rc;
         ev_end(c, h);
         ev_end(c, hb);
@@ -1593,7 +1606,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
                                    (const uint8_t *)c->d_active, (const unsigned long long *)c->d_round_walks, L,
                                    1.0 / c->n, sqrt(1.0 / c->n), c->d_upper, c->d_lower);
             // if_stop, algo.h:1096-1166
-            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 64), nb), dim3(BLOCK), 0, c->stream, dw,
+            hipLaunchKernelGGL(k_count_above, dim3(std::min<uint32_t>(chunks, 256), nb), dim3(BLOCK), 0, c->stream, dw,
                                (const uint8_t *)c->d_active, 2.0 * delta, c->d_above);
             const bool bounds_on = !(delta >= threshold);
             if (bounds_on) {

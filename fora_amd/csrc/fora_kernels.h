@@ -58,6 +58,26 @@ constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN
 // slabs in L2 (accumulate kernels -1 %)
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 constexpr int CSTRIDE = 32; // u32 words between hot global counters: one 128-B line each
+constexpr int SLAB_UNROLL = 4; // slab sweeps: loads in flight per lane
+// Tiles of k_pushq_bin / k_walk_idx are made of GRAN-entry granules, one from each of NT / GRAN equal segments
+// of the list, instead of NT consecutive entries: neighbouring entries are neighbouring nodes (k_accum writes the
+// frontier in node order, k_walk_alloc the items), whose rows / index walks sit side by side in memory, and a tile that
+// streams ONE contiguous stretch keeps a few memory channels busy where the granules of distant stretches spread over
+// all of them (LJ-sized, 280 indexed queries: k_walk_idx 220 -> 160 ms).
+// Granules: the wide bin kernels 64 entries (Twitter-2010-sized 657 -> 627 ms per 28 queries; 16: LJ-sized 359 -> 377 ms),
+// the narrow one keeps whole tiles (ws-sized: col is cache-resident, 38.1 ms against 39.6 with 64 and 42.8 with 16),
+// k_walk_idx 8 items (Twitter-2010-sized 563 ms whole tiles, 456 with 64, 404 with 16, 387 with 8, 384 with 4).
+#ifndef FORA_TILE_GRAN_BIN
+#define FORA_TILE_GRAN_BIN 64
+#endif
+#ifndef FORA_TILE_GRAN_WALK
+#define FORA_TILE_GRAN_WALK 8
+#endif
+// list position of entry `own` (0 .. NT-1) of tile `tile`; seg_len = tiles of the list * GRAN
+template <uint32_t GRAN>
+__device__ __forceinline__ uint32_t tile_pos(uint32_t own, uint32_t tile, uint32_t seg_len) {
+    return (own / GRAN) * seg_len + tile * GRAN + (own % GRAN);
+}
 #ifndef FORA_BIN_THREADS_WIDE
 #define FORA_BIN_THREADS_WIDE 512
 #endif
@@ -652,9 +672,12 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     }
     uint64_t acc_res = 0, acc_dang = 0, acc_pops = 0, acc_relax = 0;
     STAMP_DECL
-    for (uint32_t tbase = blockIdx.x * NT; tbase < count; tbase += gridDim.x * NT) {
+    constexpr uint32_t GRAN = WIDE ? FORA_TILE_GRAN_BIN : NT; // see tile_pos
+    const uint32_t ntiles = (count + NT - 1) / NT;
+    const uint32_t seg_len = ntiles * GRAN;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- one frontier entry per lane
-        const uint32_t i = tbase + threadIdx.x;
+        const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
         if (i < count) {
             const uint32_t v = in[i];
@@ -753,7 +776,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     const uint32_t b = (w[k] >> BS) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
                     const uint32_t own = si[k];
-                    s_msg[sp] = WIDE ? (w[k] & (BSZ - 1)) | (own << BS) : ((w[k] & (BSZ - 1)) << SEG_BITS) | (tbase + own);
+                    s_msg[sp] = WIDE ? (w[k] & (BSZ - 1)) | (own << BS) : ((w[k] & (BSZ - 1)) << SEG_BITS) | tile_pos<GRAN>(own, tile, seg_len);
                     s_bin[sp] = b;
                 }
             }
@@ -762,9 +785,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             for (uint32_t m = threadIdx.x; m < staged; m += NT) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t e = s_msg[m];
                 const uint32_t b = s_bin[m];
-                uint32_t sidx, local;
+                uint32_t sidx = 0, local;
                 if (WIDE) { sidx = e >> BS; local = e & (BSZ - 1); }
-                else { sidx = (e & ((1u << SEG_BITS) - 1)) - tbase; local = e >> SEG_BITS; }
+                else local = e >> SEG_BITS; // narrow: the word names the frontier position
                 const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk: its messages end at s_fill[b]
                 const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
                 bool parked = pos >= d.bk_cap; // sub-bucket full
@@ -776,6 +799,10 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     } else d.bk_w[at] = e;
                 }
                 if (parked) { // park the increment in the slot's overflow list, folded in by k_accum
+                    if (!WIDE) { // back from the frontier position to the entry inside the tile (inverse of tile_pos)
+                        const uint32_t fp = e & ((1u << SEG_BITS) - 1), sg = fp / seg_len;
+                        sidx = sg * GRAN + (fp - sg * seg_len - tile * GRAN);
+                    }
                     const uint32_t oi = atomicAdd(&d.ov_count[par][q * CSTRIDE], 1u);
                     if (oi < d.ov_cap) {
                         d.ov_w[(uint64_t)q * d.ov_cap + oi] = ((bin_lo + b) << BS) | local;
@@ -1306,63 +1333,89 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
     uint64_t acc_walks = 0, acc_hit = 0;
-    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-        const uint32_t v = c * BLOCK + threadIdx.x;
-        uint64_t r = 0, num = 0, incr = 0, rem = 0, iav = 0, ipos = 0;
-        uint32_t nseg = 0;
-        if (v < (uint32_t)d.n) r = d.residue[slab + v];
-        if (r) {
-            if (split) { // query.h:363-364 / query.h:561-567
-                const uint64_t keep = mulshift62(r, d.afix);
-                d.ppr[slab + v] += keep;
-                r -= keep;
-            }
-            if (MODE == ALLOC_QUERY || (MODE == ALLOC_BOUND && !with_idx)) num = walk_count(fix2d(r), check_rsum, N); // :727
-            else num = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618 / :659
-            if (num) {
-                incr = r / num;
-                rem = r - incr * num;
-                nseg = (uint32_t)((num + WALK_SEG - 1) / WALK_SEG);
-                if (with_idx) {
-                    const uint64_t icnt = d.idx_cnt[v];
-                    ipos = d.idx_off[v];
-                    if (MODE != ALLOC_QUERY) { // query.h:575-603 / :668-709
-                        const uint64_t used = cursor[slab + v];
-                        iav = icnt - used;
-                        if (iav > num) iav = num;
-                        cursor[slab + v] = used + iav;
-                        ipos += used;
-                    } else {
-                        iav = num < icnt ? num : icnt;
-                    }
-                    acc_hit += iav;
+    // SLAB_UNROLL chunks (1024 nodes) per trip, SLAB_UNROLL consecutive nodes per lane (items stay in node order: the
+    // indexed walks then read rw_idx front to back), their loads issued together.  The trip's items get their place in the
+    // slot's list with ONE atomic per workgroup: with one per wave a Twitter-2010-sized slab (650 k waves' worth of
+    // nodes, most of them with residue) sent 650 k returning atomics to the same address -- 33 ms per launch at the
+    // ~20 M/s a single address sustains.  A workgroup whose 1024 nodes hold no residue moves on at once (after a top-k
+    // round well under 1 % of a slab is non-zero).
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_base;
+    for (uint32_t c0 = blockIdx.x * SLAB_UNROLL; c0 < nchunk; c0 += gridDim.x * SLAB_UNROLL) {
+        uint64_t rr[SLAB_UNROLL];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) {
+            const uint64_t vu = (uint64_t)c0 * BLOCK + threadIdx.x * SLAB_UNROLL + u;
+            rr[u] = vu < (uint64_t)d.n ? d.residue[slab + vu] : 0;
+            any |= rr[u] != 0;
+        }
+        if (!__syncthreads_or(any)) continue;
+        uint64_t num[SLAB_UNROLL], incr[SLAB_UNROLL], rem[SLAB_UNROLL], iav[SLAB_UNROLL], ipos[SLAB_UNROLL];
+        uint32_t nseg[SLAB_UNROLL], mine = 0;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) {
+            const uint32_t v = c0 * BLOCK + threadIdx.x * SLAB_UNROLL + u;
+            uint64_t r = rr[u];
+            num[u] = 0; incr[u] = 0; rem[u] = 0; iav[u] = 0; ipos[u] = 0; nseg[u] = 0;
+            if (r) {
+                if (split) { // query.h:363-364 / query.h:561-567
+                    const uint64_t keep = mulshift62(r, d.afix);
+                    d.ppr[slab + v] += keep;
+                    r -= keep;
                 }
-                acc_walks += num;
+                if (MODE == ALLOC_QUERY || (MODE == ALLOC_BOUND && !with_idx)) num[u] = walk_count(fix2d(r), check_rsum, N); // :727
+                else num[u] = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618 / :659
+                if (num[u]) {
+                    incr[u] = r / num[u];
+                    rem[u] = r - incr[u] * num[u];
+                    nseg[u] = (uint32_t)((num[u] + WALK_SEG - 1) / WALK_SEG);
+                    if (with_idx) {
+                        const uint64_t icnt = d.idx_cnt[v];
+                        ipos[u] = d.idx_off[v];
+                        if (MODE != ALLOC_QUERY) { // query.h:575-603 / :668-709
+                            const uint64_t used = cursor[slab + v];
+                            iav[u] = icnt - used;
+                            if (iav[u] > num[u]) iav[u] = num[u];
+                            cursor[slab + v] = used + iav[u];
+                            ipos[u] += used;
+                        } else {
+                            iav[u] = num[u] < icnt ? num[u] : icnt;
+                        }
+                        acc_hit += iav[u];
+                    }
+                    acc_walks += num[u];
+                }
             }
+            mine += nseg[u];
         }
         uint32_t tot;
-        const uint32_t off = wave_excl_scan(nseg, tot);
-        if (tot) {
-            uint32_t sb = 0;
-            if (lane == 0) sb = atomicAdd(&d.wit_count[q * CSTRIDE], tot);
-            sb = __shfl(sb, 0);
-            if ((uint64_t)sb + tot > d.wit_cap) {
-                if (lane == 0) atomicOr(d.err, ERR_WIT_OVERFLOW);
-            } else {
-                for (uint32_t k = 0; k < nseg; k++) {
-                    WalkItem w;
-                    w.j0 = (uint64_t)k * WALK_SEG;
-                    const uint64_t left = num - w.j0;
-                    w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
-                    w.idx_pos = ipos + w.j0;
-                    const uint64_t a = iav > w.j0 ? iav - w.j0 : 0;
-                    w.idx_n = a < w.cnt ? (uint32_t)a : w.cnt;
-                    w.incr = incr;
-                    w.rem = rem;
-                    w.q = (uint32_t)q;
-                    w.v = v;
-                    d.wit[(uint64_t)q * d.wit_cap + sb + off + k] = w;
-                }
+        uint32_t at = block_excl_scan(mine, s_w, tot);
+        if (!tot) continue; // uniform over the workgroup
+        if (threadIdx.x == 0) {
+            const uint32_t sb = atomicAdd(&d.wit_count[q * CSTRIDE], tot);
+            if ((uint64_t)sb + tot > d.wit_cap) atomicOr(d.err, ERR_WIT_OVERFLOW);
+            s_base = sb;
+        }
+        __syncthreads();
+        const uint32_t sb = s_base;
+        if ((uint64_t)sb + tot > d.wit_cap) continue;
+        at += sb;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) {
+            for (uint32_t k = 0; k < nseg[u]; k++) {
+                WalkItem w;
+                w.j0 = (uint64_t)k * WALK_SEG;
+                const uint64_t left = num[u] - w.j0;
+                w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
+                w.idx_pos = ipos[u] + w.j0;
+                const uint64_t a = iav[u] > w.j0 ? iav[u] - w.j0 : 0;
+                w.idx_n = a < w.cnt ? (uint32_t)a : w.cnt;
+                w.incr = incr[u];
+                w.rem = rem[u];
+                w.q = (uint32_t)q;
+                w.v = c0 * BLOCK + threadIdx.x * SLAB_UNROLL + u;
+                d.wit[(uint64_t)q * d.wit_cap + at++] = w;
             }
         }
     }
@@ -1385,30 +1438,34 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
-    for (uint32_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-        const uint32_t v = c * BLOCK + threadIdx.x;
-        bool in = false;
-        uint64_t r = 0;
-        uint32_t dg = 0;
-        if (v < (uint32_t)d.n) {
-            r = d.residue[slab + v];
-            dg = d.deg[v];
-            in = r && r >= node_thr(d.t1, dg);
+    for (uint32_t c0 = blockIdx.x * SLAB_UNROLL; c0 < nchunk; c0 += gridDim.x * SLAB_UNROLL) { // see k_walk_alloc
+        uint64_t rr[SLAB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) {
+            const uint32_t vu = (c0 + u) * BLOCK + threadIdx.x;
+            rr[u] = (c0 + u < nchunk && vu < (uint32_t)d.n) ? d.residue[slab + vu] : 0;
         }
-        if (!d.binned) {
-            wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
-            continue;
-        }
-        const unsigned long long mask = __ballot(in);
-        if (!mask) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&d.fl_count[0][q * CSTRIDE], (uint32_t)__popcll(mask));
-        base = __shfl(base, 0);
-        if (in) {
-            d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
-            const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-            if (pos < (uint32_t)d.n) { d.fl[0][slab + pos] = v; d.inc_tab[0][(uint64_t)q * d.segq_cap + pos] = r; }
-            else atomicOr(d.err, ERR_WL_OVERFLOW);
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) {
+            const uint32_t v = (c0 + u) * BLOCK + threadIdx.x;
+            const uint64_t r = rr[u];
+            if (!__ballot(r != 0)) continue;
+            const bool in = r && r >= node_thr(d.t1, d.deg[v]);
+            if (!d.binned) {
+                wave_append(in, ((uint64_t)q << 32) | v, d.wl[0], &d.wl_count[0], d.wl_cap, d.err, ERR_WL_OVERFLOW);
+                continue;
+            }
+            const unsigned long long mask = __ballot(in);
+            if (!mask) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&d.fl_count[0][q * CSTRIDE], (uint32_t)__popcll(mask));
+            base = __shfl(base, 0);
+            if (in) {
+                d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
+                const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+                if (pos < (uint32_t)d.n) { d.fl[0][slab + pos] = v; d.inc_tab[0][(uint64_t)q * d.segq_cap + pos] = r; }
+                else atomicOr(d.err, ERR_WL_OVERFLOW);
+            }
         }
     }
 }
@@ -1419,8 +1476,14 @@ __global__ void __launch_bounds__(BLOCK) k_copy_slab(int32_t n, const uint64_t *
     const int q = blockIdx.y;
     if (active && !active[q]) return;
     const uint64_t slab = (uint64_t)q * n;
-    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)n; v += (uint64_t)gridDim.x * BLOCK)
-        dst[slab + v] = src[slab + v];
+    const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v0 < (uint64_t)n; v0 += step * SLAB_UNROLL) {
+        uint64_t x[SLAB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = v0 + u * step < (uint64_t)n ? src[slab + v0 + u * step] : 0;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) if (v0 + u * step < (uint64_t)n) dst[slab + v0 + u * step] = x[u];
+    }
 }
 
 // stop test of query.h:1030: kth_ppr >= (1+eps)*delta  <=>  at least k entries >= it
@@ -1430,8 +1493,14 @@ __global__ void __launch_bounds__(BLOCK) k_count_above(Dev d, const uint8_t *act
     if (!active[q]) return;
     const uint64_t slab = (uint64_t)q * d.n;
     uint64_t acc = 0;
-    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK)
-        acc += fix2d(d.ppr[slab + v]) >= T;
+    const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v0 < (uint64_t)d.n; v0 += step * SLAB_UNROLL) {
+        uint64_t x[SLAB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = v0 + u * step < (uint64_t)d.n ? d.ppr[slab + v0 + u * step] : 0;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) acc += x[u] && fix2d(x[u]) >= T; // T > 0
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&counts[q], (unsigned long long)acc);
 }
@@ -1443,19 +1512,29 @@ constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAXK = 1024;
 // ordered compaction of a slot's non-zero ppr entries for k_topk_select: block x of slot q owns the contiguous
 // node range [x*R, (x+1)*R).  grid = (X, nq), X <= 1024.
-__global__ void __launch_bounds__(BLOCK) k_nz_count(Dev d, uint32_t R, uint32_t *counts) {
+// thr != null: only entries of at least thr[q] are kept (fixed-point slabs) -- a top-k slot that stopped because k
+// entries reached (1 + eps) * delta (query.h:1030) has its k largest among those, a few thousand entries instead of
+// the millions of non-zero ones that one k_topk_select workgroup would read eight times over.
+__global__ void __launch_bounds__(BLOCK) k_nz_count(Dev d, uint32_t R, uint32_t *counts, const double *thr) {
     __shared__ uint32_t s_w[4];
     const int q = blockIdx.y;
     const uint64_t *p = d.ppr + (uint64_t)q * d.n;
     const uint32_t lo = blockIdx.x * R, hi = min((uint32_t)d.n, lo + R);
+    const double t = thr ? thr[q] : 0.0;
     uint32_t c = 0;
-    for (uint32_t v = lo + threadIdx.x; v < hi; v += BLOCK) c += p[v] != 0;
+    for (uint32_t v0 = lo + threadIdx.x; v0 < hi; v0 += BLOCK * SLAB_UNROLL) {
+        uint64_t x[SLAB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = v0 + u * BLOCK < hi ? p[v0 + u * BLOCK] : 0;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) c += x[u] != 0 && (!thr || fix2d(x[u]) >= t);
+    }
     uint32_t tot;
     (void)block_excl_scan(c, s_w, tot);
     if (threadIdx.x == 0) counts[(uint64_t)q * gridDim.x + blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(BLOCK) k_nz_write(Dev d, uint32_t R, const uint32_t *counts, uint32_t *cids,
-                                                    uint64_t *ckeys, uint32_t *ccount) {
+                                                    uint64_t *ckeys, uint32_t *ccount, const double *thr) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
     const int q = blockIdx.y;
@@ -1472,9 +1551,11 @@ __global__ void __launch_bounds__(BLOCK) k_nz_write(Dev d, uint32_t R, const uin
     __syncthreads();
     const uint32_t lo = blockIdx.x * R, hi = min((uint32_t)d.n, lo + R);
     uint32_t base = s_base;
+    const double t = thr ? thr[q] : 0.0;
     for (uint32_t v0 = lo; v0 < hi; v0 += BLOCK) {
         const uint32_t v = v0 + threadIdx.x;
-        const uint64_t x = v < hi ? p[v] : 0;
+        uint64_t x = v < hi ? p[v] : 0;
+        if (thr && x && !(fix2d(x) >= t)) x = 0;
         uint32_t tot;
         __syncthreads();
         const uint32_t off = block_excl_scan(x != 0 ? 1u : 0u, s_w, tot);
@@ -1898,8 +1979,11 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
         s_cnt[i] = 0;
         s_fill[i] = i < bin_cnt ? bkc[(uint64_t)i * sub] : 0;
     }
-    for (uint32_t tbase = blockIdx.x * NT; tbase < nitems; tbase += gridDim.x * NT) {
-        const uint32_t i = tbase + threadIdx.x;
+    constexpr uint32_t GRAN = FORA_TILE_GRAN_WALK; // see tile_pos
+    const uint32_t ntiles = (nitems + NT - 1) / NT;
+    const uint32_t seg_len = ntiles * GRAN;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
         if (i < nitems) {
             const WalkItem w = items[i];
@@ -2139,8 +2223,14 @@ __global__ void __launch_bounds__(BLOCK) k_ppr_sum(Dev d) {
     const int q = blockIdx.y;
     const uint64_t slab = (uint64_t)q * d.n;
     uint64_t acc = 0;
-    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < (uint64_t)d.n; v += (uint64_t)gridDim.x * BLOCK)
-        acc += d.ppr[slab + v];
+    const uint64_t step = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v0 < (uint64_t)d.n; v0 += step * SLAB_UNROLL) {
+        uint64_t x[SLAB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = v0 + u * step < (uint64_t)d.n ? d.ppr[slab + v0 + u * step] : 0;
+#pragma unroll
+        for (int u = 0; u < SLAB_UNROLL; u++) acc += x[u];
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&d.qs[q].ppr_sum, (unsigned long long)acc);
 }
