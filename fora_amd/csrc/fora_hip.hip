@@ -519,9 +519,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
     // tail kernel: no agent-scope fences, 4 relaxations in flight per lane): 1024: 86.3 ms, 4096: 85.2, 16384: 82.5,
     // 32768: 81.9, 131072: 163 (one workgroup per slot cannot feed the peak levels)
     // The tail runs one workgroup per slot, so it only pays while the slots alone fill the chip: with the 14 slots of a
-    // Twitter-2010-sized batch 32768 -> 2048 takes the tail from 128 ms to 11 ms per 28 queries (15.05 -> 15.81 q/s),
-    // with LJ's 140 slots 32768 and 4096 are within 1.5 %.  Default: 32768 scaled by slots / 256, at least 2048.
-    const int64_t tail_auto = std::min<int64_t>(32768, std::max<int64_t>(2048, (int64_t)nq * 128));
+    // Twitter-2010-sized batch 32768 -> 2048 takes the tail from 128 ms to 11 ms per 28 queries (15.05 -> 15.81 q/s);
+    // LJ-sized, 140 slots: 32768 -> 4096 takes it from 16.8 to 2.2 ms per 280 queries (the bucketed levels it
+    // replaces cost less).  Default: 32 x the slot count, between 2048 and 32768.
+    const int64_t tail_auto = std::min<int64_t>(32768, std::max<int64_t>(2048, (int64_t)nq * 32));
     const uint32_t tail_max = (uint32_t)(c->opt_.tail < 0 ? tail_auto : c->opt_.tail);
     bool past_peak = c->opt_.tail_always == 1; // tests: do not wait for the frontier to have been large first
     for (;; L++) {
