@@ -818,14 +818,25 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     }
     for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
     STAMP_FLUSH(0);
+    if (!first_pass) return; // only the first pass pops
+    // the slot's counters share one 128-byte line and one address takes ~20 M atomics/s: add them up over the workgroup
+    // first (Twitter-2010-sized: 128 workgroups x 16 waves x 4 counters per slot and level otherwise)
     acc_res = wave_sum(acc_res); acc_dang = wave_sum(acc_dang);
     acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
-    if (lane == 0 && acc_pops) { // (only the first pass pops)
+    __syncthreads(); // s_inc is free after the last tile
+    if (lane == 0) {
+        const int w = threadIdx.x >> 6;
+        s_inc[w * 4 + 0] = acc_res; s_inc[w * 4 + 1] = acc_dang; s_inc[w * 4 + 2] = acc_pops; s_inc[w * 4 + 3] = acc_relax;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) t += s_inc[w * 4 + threadIdx.x];
         QState *qs = &d.qs[q];
-        atomicAdd(&qs->reserved, (unsigned long long)acc_res); // rsum bookkeeping, algo.h:992
-        if (acc_dang) atomicAdd(&qs->dang[par], (unsigned long long)acc_dang);
-        atomicAdd(&qs->pops, (unsigned long long)acc_pops);
-        if (acc_relax) atomicAdd(&qs->relax, (unsigned long long)acc_relax);
+        unsigned long long *dst = threadIdx.x == 0 ? &qs->reserved : threadIdx.x == 1 ? (unsigned long long *)&qs->dang[par]
+                                  : threadIdx.x == 2 ? &qs->pops : &qs->relax; // rsum bookkeeping, algo.h:992
+        if (t) atomicAdd(dst, (unsigned long long)t);
     }
 }
 
@@ -1421,10 +1432,16 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
     }
     acc_walks = wave_sum(acc_walks);
     acc_hit = wave_sum(acc_hit);
-    if (lane == 0) {
-        if (acc_walks) atomicAdd(&qs->n_walks, (unsigned long long)acc_walks);
-        if (acc_hit) atomicAdd(&qs->n_hit, (unsigned long long)acc_hit);
-        if (MODE == ALLOC_BOUND && acc_walks) atomicAdd(&round_walks[q], (unsigned long long)acc_walks);
+    __shared__ uint64_t s_acc[BLOCK / 64][2]; // per-slot counters: one atomic per workgroup (see k_pushq_bin)
+    if (lane == 0) { s_acc[threadIdx.x >> 6][0] = acc_walks; s_acc[threadIdx.x >> 6][1] = acc_hit; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tw = 0, th = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { tw += s_acc[w][0]; th += s_acc[w][1]; }
+        if (tw) atomicAdd(&qs->n_walks, (unsigned long long)tw);
+        if (th) atomicAdd(&qs->n_hit, (unsigned long long)th);
+        if (MODE == ALLOC_BOUND && tw) atomicAdd(&round_walks[q], (unsigned long long)tw);
     }
 }
 
@@ -2213,8 +2230,15 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += BLOCK) bkc[(uint64_t)i * d.sub] = st.fill[i];
     }
+    // one atomic per workgroup: every wave of every slot adds to the same word, and one address takes ~20 M atomics/s
     const uint64_t ws = wave_sum((uint64_t)steps);
-    if ((threadIdx.x & 63) == 0 && ws) atomicAdd(d.tot_steps, (unsigned long long)ws);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (uint32_t)ws; // < 2^32 steps per wave
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long bs = (unsigned long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (bs) atomicAdd(d.tot_steps, bs);
+    }
 }
 
 // ------------------------------------------------------------------ epilogue / hooks
