@@ -1139,7 +1139,10 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     // gather behind its own s_waitcnt vmcnt(0): serialized round trips instead of two per iteration.  (Cutting the
     // sub-buckets into 64-message units dealt round-robin to the waves -- no idle lanes but a 7-step search per unit --
     // was measured: accumulate 43 -> 59 ms per 1000 ws queries.)
-    constexpr int ACC_UNROLL = 4;
+#ifndef FORA_ACC_UNROLL_WIDE
+#define FORA_ACC_UNROLL_WIDE 4
+#endif
+    constexpr int ACC_UNROLL = WIDE ? FORA_ACC_UNROLL_WIDE : 4;
     for (uint32_t x = wid; x < sub; x += NW) {
         const uint32_t n_x = s_scnt[x];
         const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
