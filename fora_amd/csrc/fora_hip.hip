@@ -122,6 +122,8 @@ struct fora_ctx {
     uint32_t bk_cap = 0, sub = 0; // capacity of one sub-bucket; sub-buckets per (slot, bin) = producer workgroups per slot
     uint32_t *d_wit_count = nullptr; // [B * CSTRIDE]
     uint32_t *d_sw = nullptr;        // [2][B * CSTRIDE] k_round_sweep: append counters, finished-workgroup tickets
+    uint32_t *d_tile_ctr = nullptr;  // [2][B * CSTRIDE] wide bin kernels: next tile of a slot (Dev::tile_ctr)
+    uint64_t bin_launches = 0;       // parity picks the counter set
     uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
     uint8_t *d_active = nullptr;
@@ -202,7 +204,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_nz_counts);
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
-    dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw);
+    dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -392,6 +394,8 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipMalloc(&c->d_wit_count, (size_t)B * 4 * CSTRIDE));
     HIPCHK(c, hipMalloc(&c->d_sw, 2 * (size_t)B * 4 * CSTRIDE));
     HIPCHK(c, hipMemset(c->d_sw, 0, 2 * (size_t)B * 4 * CSTRIDE)); // self-resetting
+    HIPCHK(c, hipMalloc(&c->d_tile_ctr, 2 * (size_t)B * 4 * CSTRIDE));
+    HIPCHK(c, hipMemset(c->d_tile_ctr, 0, 2 * (size_t)B * 4 * CSTRIDE)); // every launch zeroes the set of the next one
     HIPCHK(c, hipMalloc(&c->d_counters, N_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_qs, (size_t)B * sizeof(QState)));
     HIPCHK(c, hipMalloc(&c->d_src, (size_t)B * sizeof(int32_t)));
@@ -447,6 +451,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
     d.sw_count = c->d_sw; d.sw_done = c->d_sw ? c->d_sw + (size_t)c->B * CSTRIDE : nullptr;
+    d.tile_ctr[0] = c->d_tile_ctr; d.tile_ctr[1] = c->d_tile_ctr ? c->d_tile_ctr + (size_t)c->B * CSTRIDE : nullptr;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
     d.ov_count[0] = c->d_ov_count; d.ov_count[1] = c->d_ov_count ? c->d_ov_count + (size_t)c->B * CSTRIDE : nullptr;
     d.ov_bin[0] = c->d_ov_bin; d.ov_bin[1] = c->d_ov_bin ? c->d_ov_bin + (size_t)c->B * c->nbins : nullptr;
@@ -535,6 +540,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
                 dp.pass = lo / c->pbins;
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
+                dp.launch_par = (int32_t)(c->bin_launches++ & 1);
                 int h = ev_begin(c, 1);
                 if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), 0, c->stream, dp, L);
                 else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);

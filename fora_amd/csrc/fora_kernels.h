@@ -186,6 +186,12 @@ struct Dev {
     int32_t rounds;         // threshold rounds of the bucketed push (k_round_sweep); 1: the plain schedule
     uint32_t round_div;     // a round is left once its frontier is down to 1/round_div of its largest one (0: only when empty)
     uint32_t *sw_count, *sw_done; // [slot * CSTRIDE] k_round_sweep: entries appended / workgroups finished (both return to 0)
+    // wide bin kernels: tiles beyond a workgroup's first are dealt out through a per-slot counter, so that the workgroup
+    // that meets a hub's row (Twitter-2010-sized: up to 1.4 M edges, 170 chunks) simply takes fewer other tiles -- with
+    // 7 slots x 128 workgroups there is barely more than one round of workgroups per launch to even things out.
+    // Ping-pong by launch parity: a launch zeroes the counter the next one will use.
+    uint32_t *tile_ctr[2];        // [slot * CSTRIDE]
+    int32_t launch_par;
     int32_t pop_next;       // k_accum<false>: pop the crossing nodes for the next level (0 on the last level of a capped run)
     uint64_t segq_cap;      // = n: a frontier holds each node at most once
     // Message buckets.  Every (slot, bin) bucket is cut into `sub` sub-buckets, one per producer workgroup of the slot
@@ -637,8 +643,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         if (count) d.qs[q].levels++;          // levels in which the slot popped (this thread is the only writer in a launch)
         if (d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
     }
-    if (!count) return;
     constexpr bool WIDE = NB > MAX_BINS;
+    if (WIDE && blockIdx.x == 0 && threadIdx.x == 0) d.tile_ctr[d.launch_par ^ 1][q * CSTRIDE] = 0; // for the next launch
+    if (!count) return;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
     constexpr uint32_t BSZ = 1u << BS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
@@ -675,7 +682,11 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     constexpr uint32_t GRAN = WIDE ? FORA_TILE_GRAN_BIN : NT; // see tile_pos
     const uint32_t ntiles = (count + NT - 1) / NT;
     const uint32_t seg_len = ntiles * GRAN;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __shared__ uint32_t s_next;
+    for (uint32_t tile = blockIdx.x; tile < ntiles;) {
+        uint32_t next_tile = tile + gridDim.x; // narrow: static round-robin
+        if (WIDE && threadIdx.x == 0) // asked for now, needed after the tile: the atomic's latency is hidden
+            next_tile = gridDim.x + atomicAdd(&d.tile_ctr[d.launch_par][q * CSTRIDE], 1u);
         // ---- one frontier entry per lane
         const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
@@ -813,7 +824,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             }
             STAMP(4);
         }
+        if (WIDE && threadIdx.x == 0) s_next = next_tile;
         __syncthreads();
+        tile = WIDE ? s_next : next_tile;
         STAMP(5);
     }
     for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
