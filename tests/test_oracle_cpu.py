@@ -317,3 +317,32 @@ def test_twin_balanced_mode(oracle, small):
         assert free["rounds"] == 1 and free["rmax"] == rmax * 8
         _, _, one = oracle.twin_query_balanced(g, s, rmax, omega, seed=SEED, start_scale=1.0)
         assert one["rmax"] == rmax / 2 ** (one["rounds"] - 1) and one["rounds"] < st["rounds"]
+
+
+@pytest.mark.parametrize("rounds,div", [(2, 0), (3, 0), (2, 4), (3, 2)])
+def test_twin_threshold_rounds_keep_the_push_invariants(oracle, small_dangling, rounds, div):
+    """Threshold rounds of the twin (the engine's options "rounds" / "round_div"): whatever the schedule, the push ends
+    with every residue under its threshold (algo.h:1012), mass is conserved exactly, and the plain schedule is what the
+    other tests pin -- it is restored afterwards."""
+    g = small_dangling
+    rmax, omega = oracle.fora_setting(g.n, g.m, 0.5)
+    t1 = int(np.ceil(np.ldexp(rmax, 62)))
+    thr = (t1 * g.deg).astype(np.uint64)
+    thr[g.deg == 0] = 1
+    srcs = pick_sources(g, 4, 91)
+    plain = [oracle.twin_push(g, int(s), rmax) for s in srcs]
+    oracle.twin_set_rounds(rounds)
+    oracle.twin_set_round_div(div)
+    try:
+        for s, p in zip(srcs, plain):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (t["residue"] < thr).all()
+            assert int(t["reserve"].sum()) + int(t["residue"].sum()) == oracle.FIX_ONE
+            assert t["rsum_fix"] == int(t["residue"].sum())
+            if div == 0:
+                assert t["relax"] <= p["relax"]  # rounds that run dry never relax more edges
+    finally:
+        oracle.twin_set_rounds(1)
+        oracle.twin_set_round_div(0)
+    again = oracle.twin_push(g, int(srcs[0]), rmax)
+    assert (again["residue"] == plain[0]["residue"]).all() and again["relax"] == plain[0]["relax"]
