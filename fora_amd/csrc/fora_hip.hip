@@ -33,6 +33,7 @@ struct Tunables {
     int64_t pass_bins = MAX_BINS_WIDE; // bins handled per pass in the wide layout
     int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
+    int64_t walk_dg = 1;         // 0: online walks never use the degree-grouped copy (k_walk_dg); read by set_graph and at launch
     int64_t bkcap = 0;           // bucket capacity in messages (0: default per layout)
     int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
     int64_t tiny = 512;          // k_accum: buckets up to this many messages go by direct atomics
@@ -49,7 +50,7 @@ struct Tunables {
 };
 static const struct { const char *name; int64_t Tunables::*field; bool layout; } OPTIONS[] = {
     {"direct", &Tunables::direct, true}, {"force_wide", &Tunables::force_wide, true}, {"pass_bins", &Tunables::pass_bins, true},
-    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"bkcap", &Tunables::bkcap, true},
+    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
     {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"round_div", &Tunables::round_div, false},
@@ -85,6 +86,10 @@ struct fora_ctx {
     uint32_t *d_row_split = nullptr; // [n][npass + 1]
     int split_pbins = 0;
     uint32_t colbits = 0;
+    // degree-grouped walk copy (WalkDG): device arrays + the scalars of the struct; dg.colp == nullptr: none
+    uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr;
+    uint8_t *d_dg_T = nullptr;
+    WalkDG dg{};
 
     // params
     bool have_params = false;
@@ -188,6 +193,8 @@ template <typename T> void dfree(T *&p) {
 
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
+    dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T);
+    c->dg = WalkDG{};
     c->split_pbins = 0;
     c->n = 0; c->nnz = 0;
 }
@@ -421,6 +428,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.rowinfo = c->d_rowinfo; d.row_ptr = c->d_row_ptr; d.col = c->d_col; d.deg = c->d_deg;
     d.rp32 = c->d_rp32; d.colp = c->d_colp; d.colbits = c->colbits;
     d.colp32 = (uint64_t)c->nnz * c->colbits < (1ull << 32) ? 1 : 0;
+    d.dg = c->dg;
     d.residue = c->d_residue; d.ppr = c->d_ppr;
     d.wl[0] = c->d_wl[0]; d.wl[1] = c->d_wl[1]; d.wl_cap = c->wl_cap;
     d.seg = (PushSeg *)c->d_scratch; d.seg_cap = c->seg_cap;
@@ -694,7 +702,17 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 hipLaunchKernelGGL((k_accum<true, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0);
             }
     }
-    hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, c->binned && !d.wide ? wgs : wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
+    if (c->binned && !d.wide && d.dg.colp && c->opt_.walk_dg != 0) { // narrow layout: one gather per step over the degree-grouped copy
+        const size_t lds = (size_t)3 * d.dg.nrec * 4 + (((size_t)d.dg.nblk + 3) & ~(size_t)3);
+        if (nzh) {
+            if (d.dg.bits32) hipLaunchKernelGGL((k_walk_dg<true, true>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
+            else hipLaunchKernelGGL((k_walk_dg<true, false>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
+        } else {
+            if (d.dg.bits32) hipLaunchKernelGGL((k_walk_dg<false, true>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
+            else hipLaunchKernelGGL((k_walk_dg<false, false>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
+        }
+    } else
+        hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, c->binned && !d.wide ? wgs : wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
     ev_end(c, h);
     if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets
         h = ev_begin(c, 7);
@@ -853,6 +871,7 @@ int sync_twin(fora_ctx *c) {
     w->n = c->n; w->m_attr = c->m_attr; w->nnz = c->nnz;
     w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
     w->d_rp32 = c->d_rp32; w->d_colp = c->d_colp; w->colbits = c->colbits;
+    w->dg = c->dg; // arrays owned by c
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
@@ -1053,6 +1072,100 @@ int fora_hip_device_info(fora_ctx *c, char *arch, int arch_len, int *cus, uint64
     return FORA_OK;
 }
 
+
+// Degree-grouped walk copy (WalkDG, fora_kernels.h) of graphs that run the narrow layout: H hub records + at most 255
+// out-degree classes whose tables fit a workgroup's LDS share.  Graphs that do not qualify keep k_walk_online.
+static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col) {
+    const int32_t n = c->n;
+    const int64_t nnz = c->nnz;
+    if (c->opt_.walk_dg == 0 || c->opt_.no_compact == 1 || nnz >= (1ll << 31) || nnz == 0) return FORA_OK;
+    if (!((uint64_t)n <= (uint64_t)MAX_BINS * BIN_SIZE && (uint64_t)n <= (1ull << SEG_BITS))) return FORA_OK; // narrow layout only
+    std::vector<uint32_t> order((size_t)n); // nodes by (out-degree descending, id ascending)
+    for (int32_t v = 0; v < n; v++) order[(size_t)v] = (uint32_t)v;
+    auto degree = [&](uint32_t v) { return (uint32_t)(row_ptr[v + 1] - row_ptr[v]); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return degree(a) > degree(b); });
+    // smallest hub count that leaves at most 255 distinct degrees behind it
+    uint32_t H = 0, K = 0;
+    for (uint32_t h : {256u, 512u, 1024u, 2048u, 4096u}) {
+        const uint32_t hh = std::min<uint32_t>(h, (uint32_t)n);
+        uint32_t k = 0;
+        for (size_t i = hh; i < (size_t)n; i++) if (i == hh || degree(order[i]) != degree(order[i - 1])) k++;
+        if (k <= 255) { H = hh; K = k; break; }
+    }
+    if (H == 0 && !(n <= 256)) return FORA_OK;
+    if (n <= 256) { H = (uint32_t)n; K = 0; }
+    uint32_t ts = 6;
+    while ((((uint64_t)n + 256ull * (1ull << ts)) >> ts) > 8192) ts++; // at most 8192 blocks (8 KB of LDS)
+    const uint32_t blk = 1u << ts;
+    const uint32_t nrec = H + K;
+    std::vector<uint32_t> rec((size_t)3 * nrec, 0), perm((size_t)n), inv;
+    uint32_t *first = rec.data(), *rdeg = rec.data() + nrec, *base = rec.data() + 2 * (size_t)nrec;
+    std::vector<uint8_t> T;
+    uint64_t edge = 0;
+    uint32_t id = 0, zero_first = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < H; i++) { // hubs: one record each
+        const uint32_t v = order[i];
+        perm[v] = id; first[i] = id; rdeg[i] = degree(v); base[i] = (uint32_t)edge;
+        if (rdeg[i] == 0 && zero_first == 0xFFFFFFFFu) zero_first = id;
+        edge += rdeg[i]; id++;
+    }
+    uint32_t k = 0;
+    for (size_t i = H; i < (size_t)n;) { // classes, each padded to whole blocks
+        size_t j = i;
+        const uint32_t dg = degree(order[i]);
+        while (j < (size_t)n && degree(order[j]) == dg) j++;
+        const uint32_t r = H + k;
+        first[r] = id; rdeg[r] = dg; base[r] = (uint32_t)edge;
+        if (dg == 0 && zero_first == 0xFFFFFFFFu) zero_first = id;
+        for (size_t t = i; t < j; t++) perm[order[t]] = id + (uint32_t)(t - i);
+        const uint32_t cnt = (uint32_t)(j - i), padded = (cnt + blk - 1) / blk * blk;
+        for (uint32_t b = 0; b < padded / blk; b++) T.push_back((uint8_t)k);
+        edge += (uint64_t)cnt * dg;
+        id += padded;
+        i = j; k++;
+    }
+    const uint32_t np = id; // ids in use (with padding)
+    if (zero_first == 0xFFFFFFFFu) zero_first = np;
+    // every id from zero_first on must be dangling: degrees descend, so the zero class (if any) is the last one
+    uint32_t bits = 1;
+    while ((1ull << bits) < (uint64_t)np) bits++;
+    const size_t lds = (size_t)3 * nrec * 4 + T.size() + 4;
+    if (lds > 24 * 1024 || bits > 31) return FORA_OK;
+    inv.assign((size_t)np, 0);
+    for (int32_t v = 0; v < n; v++) inv[perm[(size_t)v]] = (uint32_t)v;
+    const size_t words = (size_t)(((uint64_t)nnz * bits + 31) / 32) + 2;
+    std::vector<uint32_t> pk(words, 0);
+    uint64_t e = 0;
+    for (uint32_t x = 0; x < np; x++) { // rows in copy-id order, file order inside a row
+        const uint32_t v = inv[x];
+        if (perm[v] != x) continue; // padding id
+        for (int64_t f = row_ptr[v]; f < row_ptr[v + 1]; f++, e++) {
+            const uint64_t at = e * bits;
+            const uint64_t y = (uint64_t)perm[(size_t)col[f]] << (at & 31);
+            pk[at >> 5] |= (uint32_t)y;
+            pk[(at >> 5) + 1] |= (uint32_t)(y >> 32);
+        }
+    }
+    while (T.size() & 3) T.push_back(0);
+    if (T.empty()) T.assign(4, 0);
+    HIPCHK(c, hipMalloc(&c->d_dg_perm, (size_t)n * 4));
+    HIPCHK(c, hipMalloc(&c->d_dg_inv, (size_t)np * 4));
+    HIPCHK(c, hipMalloc(&c->d_dg_colp, words * 4));
+    HIPCHK(c, hipMalloc(&c->d_dg_rec, std::max<size_t>(1, rec.size()) * 4));
+    HIPCHK(c, hipMalloc(&c->d_dg_T, T.size()));
+    HIPCHK(c, hipMemcpy(c->d_dg_perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dg_inv, inv.data(), (size_t)np * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dg_colp, pk.data(), words * 4, hipMemcpyHostToDevice));
+    if (!rec.empty()) HIPCHK(c, hipMemcpy(c->d_dg_rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dg_T, T.data(), T.size(), hipMemcpyHostToDevice));
+    WalkDG g{};
+    g.perm = c->d_dg_perm; g.inv = c->d_dg_inv; g.colp = c->d_dg_colp; g.rec = c->d_dg_rec; g.T = c->d_dg_T;
+    g.H = H; g.nrec = nrec; g.nblk = (uint32_t)T.size(); g.ts = ts; g.bits = bits; g.zero_first = zero_first;
+    g.bits32 = (uint64_t)nnz * bits < (1ull << 32) ? 1 : 0;
+    c->dg = g;
+    return FORA_OK;
+}
+
 int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *row_ptr, const int32_t *col) {
     if (!c) return FORA_E_ARG;
     if (n <= 0 || !row_ptr || row_ptr[0] != 0) return fail(c, FORA_E_ARG, "bad graph");
@@ -1106,6 +1219,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     }
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
+    if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
     return FORA_OK;
 }
 

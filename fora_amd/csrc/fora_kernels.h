@@ -130,6 +130,25 @@ struct QState {       // per-slot accumulators
     uint32_t tshift, peak;       // bucketed push: the slot's current threshold is t1 << tshift (threshold rounds, see k_round_sweep); largest frontier of the round so far
 };
 
+// Degree-grouped copy of the graph for the online walks (k_walk_dg).  Nodes are renumbered so that the out-degree of a
+// node follows from its new id alone: ids 0 .. H-1 are the H nodes of largest out-degree, one record each; after them
+// every distinct out-degree is a class whose nodes sit side by side (ties in the original order), padded with unused
+// ids to a multiple of 2^ts, so that block (id - H) >> ts belongs to ONE class.  A row is deg consecutive entries of the
+// bit-packed target list `colp` (targets in copy ids, file order inside a row, algo.h:134-137), rows in copy-id order:
+//   first edge of id = base[r] + (id - first[r]) * deg[r],  r = id < H ? id : H + T[(id - H) >> ts]
+// with the record tables and T in LDS.  A walk step is then ONE gather (the chosen target) instead of two (row
+// offsets, then target), and the row-offset table drops out of the randomly read working set.
+struct WalkDG {
+    const uint32_t *perm; // [n] original id -> copy id
+    const uint32_t *inv;  // [np] copy id -> original id (padding ids: unused)
+    const uint32_t *colp; // bit-packed targets, `bits` bits each, read as two aligned dwords; null: no such copy
+    const uint32_t *rec;  // [3][nrec]: first copy id | out-degree | first edge, hub records 0 .. H-1, then one per class
+    const uint8_t *T;     // [nblk (rounded up to 4)] class of block (id - H) >> ts
+    uint32_t H, nrec, nblk, ts, bits;
+    uint32_t zero_first;  // first copy id of the out-degree-0 class (np when there is none): ids from here on are dangling
+    uint32_t bits32;      // != 0: bit offsets fit 32 bits
+};
+
 struct Dev {
     int32_t n;
     int32_t nq; // slots in use this batch
@@ -144,6 +163,7 @@ struct Dev {
     const uint32_t *colp;   // bit-packed column ids, entry e at bit e*colbits, read as two aligned dwords
     uint32_t colbits;
     uint32_t colp32;        // != 0: bit offsets fit 32 bits
+    WalkDG dg;              // degree-grouped copy (narrow layout, see k_walk_dg)
     uint64_t *residue, *ppr;
     uint64_t *wl[2];
     uint64_t wl_cap;
@@ -1900,6 +1920,7 @@ struct WaveStage {
     uint32_t *fill;  // [MAX_BINS] of the WORKGROUP: messages in its sub-bucket of every bin (see Dev::bk_w)
     uint32_t count;  // wave-uniform
 };
+template <int ST>
 __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) {
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
@@ -1909,10 +1930,10 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     st.bcnt[lane + 64] = 0;
     __builtin_amdgcn_wave_barrier();
     constexpr uint64_t NONE = ~0ull;
-    uint32_t rk[STAGE / 64];
-    uint64_t wv[STAGE / 64];
+    uint32_t rk[ST / 64];
+    uint64_t wv[ST / 64];
 #pragma unroll
-    for (int k = 0; k < STAGE / 64; k++) {
+    for (int k = 0; k < ST / 64; k++) {
         const uint32_t m = k * 64 + lane;
         wv[k] = NONE;
         if (m < st.count) {
@@ -1935,11 +1956,11 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     // sort the stage by bin in place (every entry is in registers), so that consecutive lanes store to consecutive
     // bucket slots: one write request per run instead of one per walk
 #pragma unroll
-    for (int k = 0; k < STAGE / 64; k++)
+    for (int k = 0; k < ST / 64; k++)
         if (wv[k] != NONE) st.pk[st.bcnt[((uint32_t)wv[k] & ((1u << WPACK_SHIFT) - 1)) >> BIN_SHIFT] + rk[k]] = wv[k];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < STAGE / 64; k++) {
+    for (int k = 0; k < ST / 64; k++) {
         const uint32_t m = k * 64 + lane;
         if (m < st.count) {
             const uint64_t pk = st.pk[m];
@@ -1953,6 +1974,7 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
     __builtin_amdgcn_wave_barrier();
     st.count = 0;
 }
+template <int ST>
 __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, bool has, uint32_t dest, uint64_t w) {
     if (has && w >= WPACK_MAXW) { // does not fit the packed word (tiny walk budgets only)
         atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + dest], (unsigned long long)w);
@@ -1965,16 +1987,17 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
         st.pk[pos] = (uint64_t)dest | (w << WPACK_SHIFT);
     }
     st.count += (uint32_t)__popcll(mask);
-    if (st.count > STAGE - 64) stage_flush(d, q, st);
+    if (st.count > ST - 64) stage_flush<ST>(d, q, st);
 }
-#define WAVE_STAGE_DECL(st)                                                                         \
-    __shared__ uint64_t st##_pk[BLOCK / 64][STAGE];                                                 \
-    __shared__ uint32_t st##_bcnt[BLOCK / 64][MAX_BINS], st##_bbase[BLOCK / 64][MAX_BINS];         \
+#define WAVE_STAGE_DECL_N(st, NWAVES, ST)                                                           \
+    __shared__ uint64_t st##_pk[NWAVES][ST];                                                        \
+    __shared__ uint32_t st##_bcnt[NWAVES][MAX_BINS], st##_bbase[NWAVES][MAX_BINS];                 \
     __shared__ uint32_t st##_fill[MAX_BINS];                                                        \
     WaveStage st;                                                                                   \
     st.pk = st##_pk[threadIdx.x >> 6];                                                              \
     st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6];                 \
     st.fill = st##_fill; st.count = 0;
+#define WAVE_STAGE_DECL(st) WAVE_STAGE_DECL_N(st, BLOCK / 64, STAGE)
 
 // ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
 // are read from rw_idx.  Streaming gather; grid = (X, nq).  With the bucketed layouts the results
@@ -2233,7 +2256,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
                 }
             }
             if (staged) {
-                stage_emit(d, q, st, done >= 0, (uint32_t)done, wgt);                             // query.h:299,322
+                stage_emit<STAGE>(d, q, st, done >= 0, (uint32_t)done, wgt);                      // query.h:299,322
             } else if (done >= 0) {
                 if (MODE == WALK_TO_INDEX) idx_out[opos] = done;                                  // build.h:346-353
                 else atomicAdd((unsigned long long *)&d.ppr[slab + (uint32_t)done], (unsigned long long)wgt);
@@ -2241,7 +2264,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
         }
         __syncthreads();
     }
-    if (staged && st.count) stage_flush(d, q, st);
+    if (staged && st.count) stage_flush<STAGE>(d, q, st);
     if (staged) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += BLOCK) bkc[(uint64_t)i * d.sub] = st.fill[i];
@@ -2253,6 +2276,170 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long bs = (unsigned long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (bs) atomicAdd(d.tot_steps, bs);
+    }
+}
+
+// ---- online walks over the degree-grouped copy (WalkDG; narrow layout, results staged per wave).  grid = (sub, nq),
+// DG_THREADS threads.  Same walks as k_walk_online bit for bit: the Philox counter keeps the ORIGINAL id of the start
+// node, rows keep file order, so walk j of a node takes the same edges and ends at the same node.  What changes is the
+// cost of a step: the out-degree and first edge of the current node come from its copy id and two LDS reads (block ->
+// class, class record), so a step is ONE divergent gather (the packed target) instead of two dependent ones, and the
+// 1.1 MB of row offsets leave the gathered working set (ws-sized: 6.6 -> 5.5 MB against 4 MB of L2 per XCD).  An
+// iteration runs both steps of a Philox call; the endpoint's original id (one gather per WALK) is loaded at the end
+// of the iteration and consumed by the next one's emission, so its latency hides behind the refill and the Philox
+// rounds.  A workgroup is 8 waves sharing one copy of the tables.
+#ifndef FORA_DG_THREADS
+#define FORA_DG_THREADS 512
+#endif
+#ifndef FORA_DG_STAGE
+#define FORA_DG_STAGE 256
+#endif
+#ifndef FORA_DG_WPE
+#define FORA_DG_WPE 6
+#endif
+constexpr int DG_THREADS = FORA_DG_THREADS;
+constexpr int DG_STAGE = FORA_DG_STAGE;
+constexpr int DG_TILE = 256; // walk items per tile
+template <bool BITS32>
+__device__ __forceinline__ uint32_t dg_colp_at(const WalkDG &g, uint32_t e) {
+    uint32_t word, sh;
+    if (BITS32) { const uint32_t at = g.bits * e; word = at >> 5; sh = at & 31; }
+    else { const uint64_t at = (uint64_t)g.bits * e; word = (uint32_t)(at >> 5); sh = (uint32_t)at & 31; }
+    const U32Pair cw = *(const U32Pair *)(g.colp + word);
+    const uint64_t both = ((uint64_t)cw.b << 32) | cw.a;
+    return (uint32_t)(both >> sh) & ((1u << g.bits) - 1u);
+}
+template <bool NZH, bool BITS32>
+__global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(FORA_DG_WPE, 8))) k_walk_dg(Dev d, uint32_t round) {
+    constexpr int NW = DG_THREADS / 64;
+    extern __shared__ uint32_t dg_lds[]; // first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
+    __shared__ uint64_t s_j0[DG_TILE], s_incr[DG_TILE], s_rem[DG_TILE];
+    __shared__ uint32_t s_v[DG_TILE], s_vp[DG_TILE], s_idxn[DG_TILE], s_pref[DG_TILE + 1], s_w[NW];
+    const int q = blockIdx.y;
+    const uint32_t nitems = d.wit_count[q * CSTRIDE];
+    if (!nitems) return;
+    const WalkDG &g = d.dg;
+    const uint32_t *s_first = dg_lds, *s_deg = dg_lds + g.nrec, *s_base = dg_lds + 2 * g.nrec;
+    const uint8_t *s_T = (const uint8_t *)(dg_lds + 3 * g.nrec);
+    for (uint32_t i = threadIdx.x; i < 3 * g.nrec; i += DG_THREADS) dg_lds[i] = g.rec[i];
+    for (uint32_t i = threadIdx.x; i < (g.nblk + 3) / 4; i += DG_THREADS) dg_lds[3 * g.nrec + i] = ((const uint32_t *)g.T)[i];
+    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const uint32_t stream = (uint32_t)d.src[q];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t H = g.H, ts = g.ts;
+    uint32_t steps = 0;
+    WAVE_STAGE_DECL_N(st, NW, DG_STAGE)
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * d.sub + blockIdx.x; // count of bin b: bkc[b * sub]
+    for (uint32_t i = threadIdx.x; i < (uint32_t)MAX_BINS; i += DG_THREADS) st.fill[i] = i < (uint32_t)d.nbins ? bkc[(uint64_t)i * d.sub] : 0;
+    __syncthreads();
+    // one move (algo.h:134-140) from copy id `cur` with random word wm
+    auto move = [&](uint32_t cur, uint32_t startp, uint32_t wm) -> uint32_t {
+        const bool hub = cur < H;
+        const uint32_t r = hub ? cur : H + s_T[(cur - H) >> ts];
+        const uint32_t dg = s_deg[r];
+        const uint32_t e = s_base[r] + (cur - s_first[r]) * dg + __umulhi(wm, dg);
+        const uint32_t nx = dg_colp_at<BITS32>(g, dg ? e : 0u);
+        return dg ? nx : startp;
+    };
+    // result waiting for its original id (loaded at the end of the previous iteration)
+    bool pend = false;
+    uint32_t pend_node = 0;
+    uint64_t pend_w = 0;
+    for (uint32_t tbase = blockIdx.x * DG_TILE; tbase < nitems; tbase += gridDim.x * DG_TILE) {
+        const uint32_t i = tbase + threadIdx.x;
+        uint32_t cnt = 0;
+        if (threadIdx.x < DG_TILE && i < nitems) {
+            const WalkItem w = items[i];
+            s_j0[threadIdx.x] = w.j0; s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
+            s_v[threadIdx.x] = w.v;
+            s_vp[threadIdx.x] = g.perm[w.v];
+            s_idxn[threadIdx.x] = w.idx_n;
+            cnt = w.cnt - w.idx_n;
+        }
+        uint32_t total;
+        const uint32_t pre = block_excl_scan_n<DG_THREADS>(cnt, s_w, total);
+        if (threadIdx.x < DG_TILE) s_pref[threadIdx.x] = pre;
+        if (threadIdx.x == 0) s_pref[DG_TILE] = total;
+        __syncthreads();
+        const uint32_t wend = (uint32_t)(((uint64_t)total * (wid + 1)) / NW);
+        uint32_t wptr = (uint32_t)(((uint64_t)total * wid) / NW); // next unassigned walk of this wave
+        uint32_t cur_item = 0;                                      // item holding walk wptr (wave-uniform)
+        {
+            uint32_t hi = DG_TILE;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint32_t mid = (cur_item + hi) >> 1;
+                if (s_pref[mid] <= wptr) cur_item = mid; else hi = mid;
+            }
+        }
+        bool active = false;
+        uint32_t cur = 0, start = 0, startp = 0, t = 0;
+        uint64_t wj = 0, wgt = 0;
+        for (;;) {
+            int32_t done = -1; // endpoint (copy id) reached this iteration
+            const unsigned long long idle = __ballot(!active);
+            const uint32_t avail = wend - wptr;
+            if (!avail && idle == ~0ull) break;
+            if (avail && idle) {
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1));
+                if (!active && rank < avail) {
+                    const uint32_t e = wptr + rank;
+                    uint32_t item = cur_item;
+                    while (s_pref[item + 1] <= e) item++;
+                    const uint32_t jj = s_idxn[item] + (e - s_pref[item]); // online walks follow the indexed ones
+                    wj = s_j0[item] + jj;
+                    start = s_v[item];
+                    startp = s_vp[item];
+                    wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // the lane's previous result already waits in pend_w
+                    cur = startp;
+                    t = 0;
+                    if (startp >= g.zero_first) done = (int32_t)startp; // algo.h:127-129
+                    else active = true;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                wptr += want < avail ? want : avail;
+                while (wptr < wend && s_pref[cur_item + 1] <= wptr) cur_item++;
+            }
+            if (active) {
+                uint32_t rw[4];
+                philox4x32_10(start, (uint32_t)wj,
+                              (uint32_t)((wj >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
+                              stream ^ ((t >> 9) * 0x9E3779B9u), d.seed_lo, d.seed_hi, rw);
+                if (!(NZH && t == 0) && rw[0] < d.alpha32) { // algo.h:131-133
+                    done = (int32_t)cur;
+                    active = false;
+                } else {
+                    cur = move(cur, startp, rw[1]);
+                    steps++;
+                    if (rw[2] < d.alpha32) {
+                        t++;
+                        done = (int32_t)cur;
+                        active = false;
+                    } else {
+                        cur = move(cur, startp, rw[3]);
+                        t += 2;
+                        steps++;
+                    }
+                }
+            }
+            stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w); // query.h:299,322
+            pend = done >= 0;
+            if (pend) { pend_node = g.inv[done]; pend_w = wgt; }
+        }
+        __syncthreads();
+    }
+    stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
+    if (st.count) stage_flush<DG_STAGE>(d, q, st);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += DG_THREADS) bkc[(uint64_t)i * d.sub] = st.fill[i];
+    const uint64_t ws = wave_sum((uint64_t)steps);
+    if (lane == 0) s_w[wid] = (uint32_t)ws; // < 2^32 steps per wave
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bs = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) bs += s_w[w];
         if (bs) atomicAdd(d.tot_steps, bs);
     }
 }
