@@ -33,7 +33,8 @@ struct Tunables {
     int64_t pass_bins = MAX_BINS_WIDE; // bins handled per pass in the wide layout
     int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
-    int64_t walk_dg = 1;         // 0: online walks never use the degree-grouped copy (k_walk_dg); read by set_graph and at launch
+    int64_t walk_dg = 2;         // online walks over the degree-grouped copy (k_walk_dg): 0 never, 1 with one gather per walk for the endpoint's id, 2 results in bucket order; read by set_graph and at launch
+    int64_t dg_hubs = 0;         // hub records of that copy (0: the fewest that leave <= 255 degree classes); read by set_graph
     int64_t bkcap = 0;           // bucket capacity in messages (0: default per layout)
     int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
     int64_t tiny = 512;          // k_accum: buckets up to this many messages go by direct atomics
@@ -50,7 +51,7 @@ struct Tunables {
 };
 static const struct { const char *name; int64_t Tunables::*field; bool layout; } OPTIONS[] = {
     {"direct", &Tunables::direct, true}, {"force_wide", &Tunables::force_wide, true}, {"pass_bins", &Tunables::pass_bins, true},
-    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"bkcap", &Tunables::bkcap, true},
+    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
     {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"round_div", &Tunables::round_div, false},
@@ -87,7 +88,7 @@ struct fora_ctx {
     int split_pbins = 0;
     uint32_t colbits = 0;
     // degree-grouped walk copy (WalkDG): device arrays + the scalars of the struct; dg.colp == nullptr: none
-    uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr;
+    uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr, *d_dg_invb = nullptr;
     uint8_t *d_dg_T = nullptr;
     WalkDG dg{};
 
@@ -193,7 +194,7 @@ template <typename T> void dfree(T *&p) {
 
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
-    dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T);
+    dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
     c->n = 0; c->nnz = 0;
@@ -296,7 +297,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
     p.wits = n + n / WALK_SEG + (uint64_t)(walks / WALK_SEG) + 64;
     if (p.binned) {
         p.nbins = (int)bins_of(c);
-        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c, p.nbins)) : p.nbins;
+        p.pbins = want_wide(c) ? std::min(p.nbins, want_pass_bins(c, p.nbins)) : std::max(p.nbins, (int)c->dg.nbx); // narrow: the walk results in bucket order may need a bin more
         p.sub = want_sub(c, slots);
         { // capacity of one sub-bucket: the bucket's capacity over its sub-buckets (+25 % for uneven producers); the
           // `bkcap` option (tests) sets it directly
@@ -702,21 +703,38 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 hipLaunchKernelGGL((k_accum<true, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0);
             }
     }
-    if (c->binned && !d.wide && d.dg.colp && c->opt_.walk_dg != 0) { // narrow layout: one gather per step over the degree-grouped copy
-        const size_t lds = (size_t)3 * d.dg.nrec * 4 + (((size_t)d.dg.nblk + 3) & ~(size_t)3);
-        if (nzh) {
-            if (d.dg.bits32) hipLaunchKernelGGL((k_walk_dg<true, true>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
-            else hipLaunchKernelGGL((k_walk_dg<true, false>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
-        } else {
-            if (d.dg.bits32) hipLaunchKernelGGL((k_walk_dg<false, true>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
-            else hipLaunchKernelGGL((k_walk_dg<false, false>), wgs, dim3(DG_THREADS), lds, c->stream, d, round);
+    const bool dg = c->binned && !d.wide && d.dg.colp && c->opt_.walk_dg != 0; // narrow layout: one gather per step over the degree-grouped copy
+    const bool xl = dg && c->opt_.walk_dg != 1 && d.dg.invb;                  // ... and results in bucket order (no gather per walk either)
+    if (xl && with_idx) { // the indexed results are in plain ids: reduce them before the buckets are reused in bucket order
+        ev_end(c, h);
+        h = ev_begin(c, 7);
+        hipLaunchKernelGGL((k_accum<true, false>), dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
+        ev_end(c, h);
+        h = ev_begin(c, 3);
+    }
+    Dev dw = d;
+    if (xl) { dw.nbins = (int32_t)d.dg.nbx; dw.acc_xl = d.dg.invb; }
+    if (dg) {
+        const size_t lds = (xl ? (size_t)d.dg.H * 8 : 0) + (size_t)3 * d.dg.nrec * 4 + (((size_t)d.dg.nblk + 3) & ~(size_t)3);
+#define FORA_DG_LAUNCH(NZH, B32, XLF) hipLaunchKernelGGL((k_walk_dg<NZH, B32, XLF>), wgs, dim3(DG_THREADS), lds, c->stream, dw, round)
+        const int sel = (nzh ? 4 : 0) | (d.dg.bits32 ? 2 : 0) | (xl ? 1 : 0);
+        switch (sel) {
+        case 0: FORA_DG_LAUNCH(false, false, false); break;
+        case 1: FORA_DG_LAUNCH(false, false, true); break;
+        case 2: FORA_DG_LAUNCH(false, true, false); break;
+        case 3: FORA_DG_LAUNCH(false, true, true); break;
+        case 4: FORA_DG_LAUNCH(true, false, false); break;
+        case 5: FORA_DG_LAUNCH(true, false, true); break;
+        case 6: FORA_DG_LAUNCH(true, true, false); break;
+        default: FORA_DG_LAUNCH(true, true, true); break;
         }
+#undef FORA_DG_LAUNCH
     } else
         hipLaunchKernelGGL(k_walk_online<WALK_TO_PPR>, c->binned && !d.wide ? wgs : wg, dim3(BLOCK), 0, c->stream, d, round, nzh, (int32_t *)nullptr);
     ev_end(c, h);
-    if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets
+    if (c->binned && !d.wide) { // narrow layout: indexed and online results share the buckets (bucket-order results: see above)
         h = ev_begin(c, 7);
-        hipLaunchKernelGGL((k_accum<true, false>), dim3(c->nbins, nq), dim3(ACC_THREADS), 0, c->stream, d, 0);
+        hipLaunchKernelGGL((k_accum<true, false>), dim3(dw.nbins, nq), dim3(ACC_THREADS), 0, c->stream, dw, 0);
         ev_end(c, h);
     }
 }
@@ -1087,6 +1105,7 @@ static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col
     // smallest hub count that leaves at most 255 distinct degrees behind it
     uint32_t H = 0, K = 0;
     for (uint32_t h : {256u, 512u, 1024u, 2048u, 4096u}) {
+        if (c->opt_.dg_hubs > 0 && (int64_t)h < c->opt_.dg_hubs) continue;
         const uint32_t hh = std::min<uint32_t>(h, (uint32_t)n);
         uint32_t k = 0;
         for (size_t i = hh; i < (size_t)n; i++) if (i == hh || degree(order[i]) != degree(order[i - 1])) k++;
@@ -1129,8 +1148,8 @@ static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col
     // every id from zero_first on must be dangling: degrees descend, so the zero class (if any) is the last one
     uint32_t bits = 1;
     while ((1ull << bits) < (uint64_t)np) bits++;
-    const size_t lds = (size_t)3 * nrec * 4 + T.size() + 4;
-    if (lds > 24 * 1024 || bits > 31) return FORA_OK;
+    const size_t lds = (size_t)H * 8 + (size_t)3 * nrec * 4 + T.size() + 4;
+    if (lds > 28 * 1024 || bits > 31) return FORA_OK; // static + dynamic LDS of k_walk_dg stay under 64 KB
     inv.assign((size_t)np, 0);
     for (int32_t v = 0; v < n; v++) inv[perm[(size_t)v]] = (uint32_t)v;
     const size_t words = (size_t)(((uint64_t)nnz * bits + 31) / 32) + 2;
@@ -1158,7 +1177,20 @@ static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col
     HIPCHK(c, hipMemcpy(c->d_dg_colp, pk.data(), words * 4, hipMemcpyHostToDevice));
     if (!rec.empty()) HIPCHK(c, hipMemcpy(c->d_dg_rec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_dg_T, T.data(), T.size(), hipMemcpyHostToDevice));
+    // bucket order of the ids behind the hubs: 64-id blocks dealt round-robin to nbx bins
+    const uint32_t nblk64 = (np - H + 63) / 64;
+    const uint32_t nbx = std::max<uint32_t>(2, (nblk64 + 127) / 128); // (2 at least: floor(2^32 / nbx) + 1 must fit 32 bits)
+    std::vector<uint32_t> invb((size_t)nbx * BIN_SIZE, 0);
+    for (uint32_t x = H; x < np; x++) {
+        const uint32_t u = x - H, b64 = u >> 6;
+        invb[((size_t)(b64 % nbx) << BIN_SHIFT) | ((b64 / nbx) << 6) | (u & 63u)] = inv[x];
+    }
+    if (nbx <= (uint32_t)MAX_BINS) {
+        HIPCHK(c, hipMalloc(&c->d_dg_invb, invb.size() * 4));
+        HIPCHK(c, hipMemcpy(c->d_dg_invb, invb.data(), invb.size() * 4, hipMemcpyHostToDevice));
+    }
     WalkDG g{};
+    g.invb = c->d_dg_invb; g.nbx = c->d_dg_invb ? nbx : 0; g.nbx_magic = (uint32_t)((1ull << 32) / nbx) + 1;
     g.perm = c->d_dg_perm; g.inv = c->d_dg_inv; g.colp = c->d_dg_colp; g.rec = c->d_dg_rec; g.T = c->d_dg_T;
     g.H = H; g.nrec = nrec; g.nblk = (uint32_t)T.size(); g.ts = ts; g.bits = bits; g.zero_first = zero_first;
     g.bits32 = (uint64_t)nnz * bits < (1ull << 32) ? 1 : 0;

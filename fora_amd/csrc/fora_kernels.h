@@ -147,6 +147,13 @@ struct WalkDG {
     uint32_t H, nrec, nblk, ts, bits;
     uint32_t zero_first;  // first copy id of the out-degree-0 class (np when there is none): ids from here on are dangling
     uint32_t bits32;      // != 0: bit offsets fit 32 bits
+    // Results without a gather per walk (k_walk_dg<.., XL = true>): an endpoint among the H hubs -- a quarter to a third of
+    // all endpoints -- is added to per-workgroup LDS accumulators (flushed with H atomics per workgroup); the others
+    // travel in BUCKET ORDER: the 64-id blocks behind the hubs are dealt round-robin to nbx bins of BIN_SIZE entries
+    // (copy ids descend by degree, whole ranges of them are hot: contiguous bins would be badly skewed), word =
+    // bin << BIN_SHIFT | local, and k_accum<true> finds the original id of (bin, local) in `invb`, read front to back.
+    const uint32_t *invb; // [nbx * BIN_SIZE] bucket order -> original id (unused entries: never touched)
+    uint32_t nbx, nbx_magic; // bins of the bucket order; floor(2^32 / nbx) + 1 (exact block / nbx for block < 2^16)
 };
 
 struct Dev {
@@ -164,6 +171,7 @@ struct Dev {
     uint32_t colbits;
     uint32_t colp32;        // != 0: bit offsets fit 32 bits
     WalkDG dg;              // degree-grouped copy (narrow layout, see k_walk_dg)
+    const uint32_t *acc_xl; // k_accum<true>: the buckets hold results in WalkDG bucket order, original id = acc_xl[bin << BIN_SHIFT | local]; null: plain ids
     uint64_t *residue, *ppr;
     uint64_t *wl[2];
     uint64_t wl_cap;
@@ -1088,6 +1096,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const uint32_t s = (uint32_t)d.src[q];
     const uint64_t dm = (!TO_PPR && (int)(s >> BS) == b) ? (uint64_t)d.qs[q].dang[par] : 0; // algo.h:994
     uint64_t *target = TO_PPR ? d.ppr : d.residue;
+    const uint32_t *xl = TO_PPR ? d.acc_xl : nullptr; // walk results in WalkDG bucket order: original id = xl[bin << BS | local]
     __syncthreads();
     const uint32_t cnt = s_total;
     if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
@@ -1131,7 +1140,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
                     }
                 } else if (i < n_x) { w = s; inc = dm; }
                 if (inc) {
-                    const uint64_t old = atomicAdd((unsigned long long *)&target[slab + w], (unsigned long long)inc);
+                    const uint64_t old = atomicAdd((unsigned long long *)&target[slab + (TO_PPR && xl ? xl[w] : w)], (unsigned long long)inc);
                     if (!TO_PPR) {
                         const uint64_t thr = node_thr(t1q, d.deg[w]);
                         cross = old < thr && old + inc >= thr; // increments are positive: exactly one add crosses
@@ -1217,6 +1226,17 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         uint32_t dg[SWEEP];
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) v[k] = acc[k * AT + threadIdx.x];
+        if (TO_PPR && xl) { // bucket order -> original ids (consecutive lanes read consecutive table entries; the adds scatter)
+#pragma unroll
+            for (int k = 0; k < SWEEP; k++) dg[k] = v[k] ? xl[node0 + k * AT + threadIdx.x] : 0u;
+#pragma unroll
+            for (int k = 0; k < SWEEP; k++) if (v[k]) old[k] = target[slab + dg[k]];
+#pragma unroll
+            for (int k = 0; k < SWEEP; k++) if (v[k]) target[slab + dg[k]] = old[k] + v[k]; // one bucket-order entry per node: this lane owns the word
+            STAMP(18);
+            STAMP_FLUSH(16);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
             old[k] = 0; dg[k] = 0;
@@ -1919,6 +1939,7 @@ struct WaveStage {
     uint32_t *bbase; // [MAX_BINS]
     uint32_t *fill;  // [MAX_BINS] of the WORKGROUP: messages in its sub-bucket of every bin (see Dev::bk_w)
     uint32_t count;  // wave-uniform
+    const uint32_t *xl; // not null: destinations are in WalkDG bucket order, original id = xl[dest] (only the direct-atomic fallbacks need it)
 };
 template <int ST>
 __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) {
@@ -1968,7 +1989,7 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
             const uint32_t b = dd >> BIN_SHIFT;
             const uint32_t pos = st.bbase[b] + (m - st.bcnt[b]);
             if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * bstride + pos] = pk;
-            else atomicAdd((unsigned long long *)&d.ppr[slab + dd], (unsigned long long)(pk >> WPACK_SHIFT)); // bucket full
+            else atomicAdd((unsigned long long *)&d.ppr[slab + (st.xl ? st.xl[dd] : dd)], (unsigned long long)(pk >> WPACK_SHIFT)); // bucket full
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1977,7 +1998,7 @@ __device__ __forceinline__ void stage_flush(const Dev &d, int q, WaveStage &st) 
 template <int ST>
 __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, bool has, uint32_t dest, uint64_t w) {
     if (has && w >= WPACK_MAXW) { // does not fit the packed word (tiny walk budgets only)
-        atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + dest], (unsigned long long)w);
+        atomicAdd((unsigned long long *)&d.ppr[(uint64_t)q * d.n + (st.xl ? st.xl[dest] : dest)], (unsigned long long)w);
         has = false;
     }
     const unsigned long long mask = __ballot(has);
@@ -1996,7 +2017,7 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
     WaveStage st;                                                                                   \
     st.pk = st##_pk[threadIdx.x >> 6];                                                              \
     st.bcnt = st##_bcnt[threadIdx.x >> 6]; st.bbase = st##_bbase[threadIdx.x >> 6];                 \
-    st.fill = st##_fill; st.count = 0;
+    st.fill = st##_fill; st.count = 0; st.xl = nullptr;
 #define WAVE_STAGE_DECL(st) WAVE_STAGE_DECL_N(st, BLOCK / 64, STAGE)
 
 // ---- indexed part of the refinement (query.h:290-296, 301-306): walks jj < idx_n of an item
@@ -2310,26 +2331,31 @@ __device__ __forceinline__ uint32_t dg_colp_at(const WalkDG &g, uint32_t e) {
     const uint64_t both = ((uint64_t)cw.b << 32) | cw.a;
     return (uint32_t)(both >> sh) & ((1u << g.bits) - 1u);
 }
-template <bool NZH, bool BITS32>
+template <bool NZH, bool BITS32, bool XL>
 __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(FORA_DG_WPE, 8))) k_walk_dg(Dev d, uint32_t round) {
     constexpr int NW = DG_THREADS / 64;
-    extern __shared__ uint32_t dg_lds[]; // first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
+    extern __shared__ uint64_t dg_lds64[]; // XL: hub accumulators [H] (u64) | first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
     __shared__ uint64_t s_j0[DG_TILE], s_incr[DG_TILE], s_rem[DG_TILE];
     __shared__ uint32_t s_v[DG_TILE], s_vp[DG_TILE], s_idxn[DG_TILE], s_pref[DG_TILE + 1], s_w[NW];
     const int q = blockIdx.y;
     const uint32_t nitems = d.wit_count[q * CSTRIDE];
     if (!nitems) return;
     const WalkDG &g = d.dg;
+    const uint32_t H = g.H, ts = g.ts;
+    unsigned long long *s_hub = (unsigned long long *)dg_lds64;
+    uint32_t *dg_lds = (uint32_t *)(dg_lds64 + (XL ? H : 0));
     const uint32_t *s_first = dg_lds, *s_deg = dg_lds + g.nrec, *s_base = dg_lds + 2 * g.nrec;
     const uint8_t *s_T = (const uint8_t *)(dg_lds + 3 * g.nrec);
     for (uint32_t i = threadIdx.x; i < 3 * g.nrec; i += DG_THREADS) dg_lds[i] = g.rec[i];
     for (uint32_t i = threadIdx.x; i < (g.nblk + 3) / 4; i += DG_THREADS) dg_lds[3 * g.nrec + i] = ((const uint32_t *)g.T)[i];
+    if (XL) for (uint32_t i = threadIdx.x; i < H; i += DG_THREADS) s_hub[i] = 0;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t stream = (uint32_t)d.src[q];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint32_t H = g.H, ts = g.ts;
     uint32_t steps = 0;
     WAVE_STAGE_DECL_N(st, NW, DG_STAGE)
+    if (XL) st.xl = g.invb;
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * d.sub + blockIdx.x; // count of bin b: bkc[b * sub]
     for (uint32_t i = threadIdx.x; i < (uint32_t)MAX_BINS; i += DG_THREADS) st.fill[i] = i < (uint32_t)d.nbins ? bkc[(uint64_t)i * d.sub] : 0;
     __syncthreads();
@@ -2342,7 +2368,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
         const uint32_t nx = dg_colp_at<BITS32>(g, dg ? e : 0u);
         return dg ? nx : startp;
     };
-    // result waiting for its original id (loaded at the end of the previous iteration)
+    // !XL: result waiting for its original id (loaded at the end of the previous iteration)
     bool pend = false;
     uint32_t pend_node = 0;
     uint64_t pend_w = 0;
@@ -2391,7 +2417,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                     wj = s_j0[item] + jj;
                     start = s_v[item];
                     startp = s_vp[item];
-                    wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // the lane's previous result already waits in pend_w
+                    wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // (!XL: the lane's previous result already waits in pend_w)
                     cur = startp;
                     t = 0;
                     if (startp >= g.zero_first) done = (int32_t)startp; // algo.h:127-129
@@ -2423,16 +2449,30 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                     }
                 }
             }
-            stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w); // query.h:299,322
-            pend = done >= 0;
-            if (pend) { pend_node = g.inv[done]; pend_w = wgt; }
+            if (XL) { // query.h:299,322
+                const bool ended = done >= 0;
+                const uint32_t dn = (uint32_t)done;
+                if (ended && dn < H) atomicAdd(&s_hub[dn], (unsigned long long)wgt); // LDS
+                const uint32_t u = dn - H, blk = u >> 6;
+                const uint32_t qd = __umulhi(blk, g.nbx_magic);                      // blk / nbx
+                const uint32_t dest = ((blk - qd * g.nbx) << BIN_SHIFT) | (qd << 6) | (u & 63u);
+                stage_emit<DG_STAGE>(d, q, st, ended && dn >= H, dest, wgt);
+            } else {
+                stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
+                pend = done >= 0;
+                if (pend) { pend_node = g.inv[done]; pend_w = wgt; }
+            }
         }
         __syncthreads();
     }
-    stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
+    if (!XL) stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
     if (st.count) stage_flush<DG_STAGE>(d, q, st);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += DG_THREADS) bkc[(uint64_t)i * d.sub] = st.fill[i];
+    if (XL) for (uint32_t i = threadIdx.x; i < H; i += DG_THREADS) { // the hubs' share of this workgroup's walks
+        const unsigned long long hv = s_hub[i];
+        if (hv) atomicAdd((unsigned long long *)&d.ppr[slab + g.inv[i]], hv);
+    }
     const uint64_t ws = wave_sum((uint64_t)steps);
     if (lane == 0) s_w[wid] = (uint32_t)ws; // < 2^32 steps per wave
     __syncthreads();
