@@ -30,7 +30,7 @@ struct EvPair {
 struct Tunables {
     int64_t direct = 0;          // 1: the one-atomic-per-edge push (test reference)
     int64_t force_wide = 0;      // 1: wide bucket layout on small graphs too (tests)
-    int64_t pass_bins = MAX_BINS_WIDE; // bins handled per pass in the wide layout
+    int64_t pass_bins = 0;       // bins handled per pass in the wide layout (0: by graph size)
     int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
     int64_t walk_dg = 2;         // online walks over the degree-grouped copy (k_walk_dg): 0 never, 1 with one gather per walk for the endpoint's id, 2 results in bucket order; read by set_graph and at launch
@@ -45,6 +45,9 @@ struct Tunables {
     int64_t rounds = 1;          // threshold rounds of the bucketed push (k_round_sweep): 2^(rounds-1) x the threshold first; 1: plain.
                                  // 2 rounds relax 17 % fewer edges (ws) but need 99 instead of 61 level launches: push 88 -> 126 ms per 1000 queries
     int64_t round_div = 4;       // leave a threshold round once the frontier is down to 1/round_div of the round's largest (0: when it is empty)
+    int64_t defer = 0;           // bounded deferral of the bucketed push (Dev::defer_k): a node that crosses with less than 2^defer x its threshold waits one level; 0 (default): plain levels.
+                                 // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
+                                 // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -54,7 +57,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 static Tunables tunables_from_env() {
@@ -106,6 +109,7 @@ struct fora_ctx {
 
     // workspace
     int batch_req = 0, B = 0;
+    int B_memcap = 0; // slots that fitted the free memory when the workspace was planned (>= B)
     uint64_t *d_residue = nullptr, *d_ppr = nullptr, *d_wl[2] = {nullptr, nullptr};
     void *d_scratch = nullptr; // PushSeg list during the push, WalkItem list during the walks
     uint64_t wl_cap = 0, seg_cap = 0, wit_cap = 0;
@@ -129,6 +133,10 @@ struct fora_ctx {
     uint32_t *d_wit_count = nullptr; // [B * CSTRIDE]
     uint32_t *d_sw = nullptr;        // [2][B * CSTRIDE] k_round_sweep: append counters, finished-workgroup tickets
     uint32_t *d_tile_ctr = nullptr;  // [2][B * CSTRIDE] wide bin kernels: next tile of a slot (Dev::tile_ctr)
+    uint64_t *d_dbm = nullptr;       // [2][B][dbm_words] bounded deferral: marks of the deferred nodes (Dev::dbm)
+    uint32_t *d_dflag = nullptr;     // [2][B][nbins]
+    uint32_t *d_dl = nullptr;        // [2][B][n] k_push_tail's deferred lists
+    uint32_t dbm_words = 0;
     uint64_t bin_launches = 0;       // parity picks the counter set
     uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
@@ -213,6 +221,7 @@ void free_workspace(fora_ctx *c) {
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
+    dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -222,6 +231,7 @@ void free_workspace(fora_ctx *c) {
     if (c->h_steps_pin) (void)hipHostFree(c->h_steps_pin);
     c->h_steps_pin = nullptr;
     c->B = 0;
+    c->B_memcap = 0;
 }
 
 constexpr size_t N_COUNTERS = 2 * (size_t)(MAX_LEVELS + 2) + 2;
@@ -251,7 +261,7 @@ static int want_pass_bins(const fora_ctx *c, int nbins) {
     // re-scan of the frontier and of the walk index costs more than the shorter message runs: Twitter-2010-sized,
     // 26 queries, bins per pass 256 / 512 / 1024: 7.5 / 4.3 / 3.0 s)
     const int cap = nbins > MAX_BINS_WIDE ? MAX_BINS_HUGE : MAX_BINS_WIDE;
-    if (c->opt_.pass_bins > 0 && c->opt_.pass_bins != MAX_BINS_WIDE) return (int)std::min<int64_t>(c->opt_.pass_bins, cap);
+    if (c->opt_.pass_bins > 0) return (int)std::min<int64_t>(c->opt_.pass_bins, cap);
     if (nbins > cap) { const int np = (nbins + cap - 1) / cap; return (nbins + np - 1) / np; } // equal passes
     return cap;
 }
@@ -308,7 +318,8 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
         }
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
-        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch;
+        p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch +
+                     n * 4 * 2 + n / 4 + 64; // + deferred lists and bitmaps
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -356,22 +367,34 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     WsPlan p = plan_workspace(c, omega_hint, 1024); // bytes per slot hardly depend on the slot count (sub-bucket rounding)
+    const uint64_t n = (uint64_t)c->n;
+    // an existing workspace with the same layout is kept if it has enough slots: as many as the call can use, or as
+    // many as an automatic plan would get at most (1024)
+    auto keepable = [&](int need) {
+        if (c->B <= 0 || c->B < need) return false;
+        const WsPlan pe = plan_workspace(c, omega_hint, c->B);
+        return c->binned == pe.binned && c->pbins == pe.pbins && c->seg_cap * sizeof(PushSeg) >= (uint64_t)c->B * pe.scratch &&
+               c->wit_cap >= pe.wits && c->bk_cap == pe.bk_cap && c->sub == pe.sub;
+    };
+    {
+        // slots the call can use: its queries, at most 1024, at most what memory allowed when the workspace was planned
+        int need = c->batch_req > 0 ? c->batch_req : std::min(want_slots > 0 ? want_slots : 1024, 1024);
+        if (c->batch_req == 0 && c->B > 0 && c->B_memcap > 0) need = std::min(need, c->B_memcap);
+        if (keepable(need)) { const WsPlan pe = plan_workspace(c, omega_hint, c->B); return ensure_row_split(c, pe.nbins, pe.pbins); }
+    }
     int B = c->batch_req > 0 ? c->batch_req : 0;
     if (B == 0) {
+        // the slot count follows from the FREE memory: give the old workspace back first, or a re-plan (larger walk budget
+        // of a top-k call, other sub-bucket count, more queries) would size itself from what the old one left over
+        free_workspace(c);
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         uint64_t budget = (uint64_t)(fr * (c->opt_.pipeline == 1 ? 0.4 : 0.75)); // with option pipeline a second lane holds its own workspace
         B = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, budget / p.per_slot)); // ws, 1000 queries: 2845 q/s at 256, 3035 at 512, 3101 at 1000
     }
     B = std::max(1, B);
+    const int memcap = B;
     if (want_slots > 0 && c->batch_req == 0) B = std::min(B, std::max(want_slots, 1));
-    const uint64_t n = (uint64_t)c->n;
-    if (c->B >= B) { // an existing workspace with enough slots and the same layout is kept as it is
-        const WsPlan pe = plan_workspace(c, omega_hint, c->B);
-        if (c->binned == pe.binned && c->pbins == pe.pbins && c->seg_cap * sizeof(PushSeg) >= (uint64_t)c->B * pe.scratch && c->wit_cap >= pe.wits &&
-            c->bk_cap == pe.bk_cap && c->sub == pe.sub)
-            return ensure_row_split(c, pe.nbins, pe.pbins);
-    }
     p = plan_workspace(c, omega_hint, B);
     const uint64_t scratch = (uint64_t)B * p.scratch;
     free_workspace(c);
@@ -394,6 +417,10 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_bk_inc, (uint64_t)B * p.pbins * p.sub * p.bk_cap * 8));
         HIPCHK(c, hipMalloc(&c->d_bk_count, (size_t)B * p.pbins * p.sub * 4));
         HIPCHK(c, hipHostMalloc(&c->h_flc, (size_t)FLC_RING * B * 4 * CSTRIDE));
+        c->dbm_words = (uint32_t)((uint64_t)p.nbins << (bin_shift(c) - 6));
+        HIPCHK(c, hipMalloc(&c->d_dbm, 2 * (size_t)B * c->dbm_words * 8));
+        HIPCHK(c, hipMalloc(&c->d_dflag, 2 * (size_t)B * p.nbins * 4));
+        HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
         HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
@@ -412,6 +439,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     HIPCHK(c, hipHostMalloc(&c->h_qs_pin, (size_t)B * sizeof(QState)));
     HIPCHK(c, hipHostMalloc(&c->h_steps_pin, sizeof(unsigned long long)));
     c->B = B;
+    c->B_memcap = memcap;
     c->binned = p.binned; c->nbins = p.nbins; c->pbins = p.pbins; c->bk_cap = p.bk_cap; c->sub = p.sub; c->segq_cap = p.segq_cap;
     if (int rs = ensure_row_split(c, p.nbins, p.pbins)) return rs;
     c->wl_cap = slab;
@@ -459,6 +487,10 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.stamps = c->d_stamps;
     d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
+    d.defer_k = c->binned ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
+    d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
+    d.dflag[0] = c->d_dflag; d.dflag[1] = c->d_dflag ? c->d_dflag + (size_t)c->B * c->nbins : nullptr;
+    d.dl[0] = c->d_dl; d.dl[1] = c->d_dl ? c->d_dl + (size_t)c->B * c->n : nullptr;
     d.sw_count = c->d_sw; d.sw_done = c->d_sw ? c->d_sw + (size_t)c->B * CSTRIDE : nullptr;
     d.tile_ctr[0] = c->d_tile_ctr; d.tile_ctr[1] = c->d_tile_ctr ? c->d_tile_ctr + (size_t)c->B * CSTRIDE : nullptr;
     d.ov_w = c->d_ov_w; d.ov_inc = c->d_ov_inc; d.ov_cap = c->ov_cap;
@@ -545,6 +577,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
         if (c->binned) {
             for (int lo = 0; lo < c->nbins; lo += c->pbins) { // one pass per group of pbins bins (usually one)
                 Dev dp = d;
+                if (level_cap > 0 || d.rounds > 1) dp.defer_k = 0; // capped runs (power iteration) and threshold rounds keep plain levels
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
                 dp.pass = lo / c->pbins;
@@ -588,7 +621,10 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 empty = true;
                 const uint32_t *cnt = c->h_flc + (size_t)((K + 1) % FLC_RING) * c->B * CSTRIDE;
                 uint32_t rounds_left = 0; // word 1 of a slot's counter line: threshold rounds still to come (k_round_sweep)
-                for (int i = 0; i < nq; i++) { fmax = std::max(fmax, cnt[(size_t)i * CSTRIDE]); rounds_left = std::max(rounds_left, cnt[(size_t)i * CSTRIDE + 1]); }
+                for (int i = 0; i < nq; i++) { // word 2: nodes the level deferred (they are part of the work that is left)
+                    fmax = std::max(fmax, cnt[(size_t)i * CSTRIDE] + cnt[(size_t)i * CSTRIDE + 2]);
+                    rounds_left = std::max(rounds_left, cnt[(size_t)i * CSTRIDE + 1]);
+                }
                 empty = fmax == 0 && rounds_left == 0;
                 if (rounds_left) fmax = std::max(fmax, tail_max + 1); // k_push_tail knows the final threshold only
             } else {
@@ -601,7 +637,9 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 const int remaining = level_cap > 0 ? level_cap - next : 0;
                 if (level_cap <= 0 || remaining > 0) {
                     int h = ev_begin(c, 9);
-                    hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, d, next, remaining);
+                    Dev dt = d;
+                    if (d.rounds > 1) dt.defer_k = 0;
+                    hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, dt, next, remaining);
                     ev_end(c, h);
                     c->timing.levels++;
                 }
@@ -658,6 +696,9 @@ int reset_binned_counters(fora_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * c->sub * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_bin, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dbm, 0, 2 * (size_t)c->B * c->dbm_words * 8, c->stream)); // (a complete push leaves them clear; an aborted one may not)
+    HIPCHK(c, hipMemsetAsync(c->d_dflag, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_tile_ctr, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream)); // both parity sets, every slot: a launch only re-zeroes the slots it runs
     return FORA_OK;
 }
 
@@ -1302,6 +1343,8 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
         if (c->twin) free_workspace(c->twin);
         c->opt_ = tunables_from_env();
         c->profiling = c->opt_.profile != 0;
+        c->grid_blocks = c->opt_.grid > 0 ? (int)c->opt_.grid : 2048;
+        if (c->twin) { c->twin->opt_ = c->opt_; c->twin->grid_blocks = c->grid_blocks; }
         return FORA_OK;
     }
     for (const auto &o : OPTIONS)
@@ -1310,6 +1353,7 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
             c->opt_.*(o.field) = value;
             if (o.layout) { (void)hipSetDevice(c->device); free_workspace(c); if (c->twin) free_workspace(c->twin); }
             if (!strcmp(name, "profile")) c->profiling = value != 0;
+            if (!strcmp(name, "grid")) { c->grid_blocks = value > 0 ? (int)value : 2048; if (c->twin) c->twin->grid_blocks = c->grid_blocks; }
             return FORA_OK;
         }
     return fail(c, FORA_E_ARG, std::string("unknown option ") + name);

@@ -213,6 +213,18 @@ struct Dev {
     unsigned long long *stamps; // diagnostic builds (-DFORA_STAMPS): cycles per kernel phase, [0..15] bin kernel, [16..31] accumulate
     int32_t rounds;         // threshold rounds of the bucketed push (k_round_sweep); 1: the plain schedule
     uint32_t round_div;     // a round is left once its frontier is down to 1/round_div of its largest one (0: only when empty)
+    // Bounded deferral (option "defer", oracle/fora_twin.c twin_levels_div): a node that crosses its threshold in level
+    // L but ends the level with less than 2^defer_k times the threshold is not popped in level L + 1: it stays where it
+    // is, is marked in the slot's bitmap, and the accumulate of level L + 1 -- which owns its residue word anyway -- hands it
+    // to the frontier of level L + 2 with whatever it holds then.  Bitmaps ping-pong by level parity: the accumulate of
+    // level L reads (and clears) [L & 1], writes [(L + 1) & 1]; a word covers 64 consecutive nodes of one bin, so it has
+    // exactly one writer (the wave that sweeps those nodes).  dflag: the bin has marks at all (early exit of k_accum).
+    // Word 2 of a slot's fl_count line counts the marks for the host's termination test.  k_push_tail keeps lists (dl).
+    int32_t defer_k;        // 0: plain levels
+    uint64_t *dbm[2];       // [slot][dbm_words]
+    uint32_t dbm_words;     // per slot: nbins << (bin shift - 6)
+    uint32_t *dflag[2];     // [slot][nbins]
+    uint32_t *dl[2];        // [slot][n] k_push_tail: nodes deferred by the previous / this level
     uint32_t *sw_count, *sw_done; // [slot * CSTRIDE] k_round_sweep: entries appended / workgroups finished (both return to 0)
     // wide bin kernels: tiles beyond a workgroup's first are dealt out through a per-slot counter, so that the workgroup
     // that meets a hub's row (Twitter-2010-sized: up to 1.4 M edges, 170 chunks) simply takes fewer other tiles -- with
@@ -667,6 +679,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     const bool first_pass = d.bin_lo == 0; // graphs with more than pbins bins run several bin/accum passes per level
     if (first_pass && blockIdx.x == 0 && threadIdx.x == 0) {
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
+        d.fl_count[par ^ 1][q * CSTRIDE + 2] = 0; // ... and so does the count of nodes this level defers
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
         if (count) d.qs[q].levels++;          // levels in which the slot popped (this thread is the only writer in a launch)
         if (d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
@@ -902,15 +915,37 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
     __shared__ uint64_t s_inc[TAIL_THREADS];
     __shared__ uint32_t s_pref[TAIL_THREADS + 1];
     __shared__ uint32_t s_scan[TAIL_THREADS / 64];
-    __shared__ uint32_t s_next, s_count;
+    __shared__ uint32_t s_next, s_count, s_ndue, s_nwait, s_real;
     __shared__ unsigned long long s_dang;
+    constexpr uint32_t HOLE = 0x80000000u; // list entry of a node that crossed but waits a level (bounded deferral): skipped by the pops
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t src = (uint32_t)d.src[q];
+    const int dk = max_levels > 0 ? 0 : d.defer_k; // capped runs (power iteration) keep plain levels
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
     uint32_t levels_run = 0;
+    if (tid == 0) { s_ndue = 0; s_real = __atomic_load_n(&d.fl_count[L0 & 1][q * CSTRIDE], __ATOMIC_RELAXED); }
+    __syncthreads();
+    if (dk && __atomic_load_n(&d.fl_count[L0 & 1][q * CSTRIDE + 2], __ATOMIC_RELAXED)) {
+        // nodes the last bucketed level deferred (marks in the slot's bitmap, see Dev::dbm): they are due in this kernel's
+        // first level; from here on the deferred sets are lists
+        uint64_t *bm = d.dbm[L0 & 1] + (uint64_t)q * d.dbm_words;
+        uint32_t *due0 = d.dl[L0 & 1] + slab;
+        for (uint32_t w = tid; w < d.dbm_words; w += TAIL_THREADS) {
+            uint64_t wd = bm[w];
+            if (!wd) continue;
+            bm[w] = 0;
+            while (wd) {
+                const uint32_t bit = (uint32_t)__ffsll((long long)wd) - 1;
+                due0[atomicAdd(&s_ndue, 1u)] = (w << 6) + bit;
+                wd &= wd - 1;
+            }
+        }
+        for (uint32_t b = tid; b < (uint32_t)d.nbins; b += TAIL_THREADS) d.dflag[L0 & 1][(uint64_t)q * d.nbins + b] = 0;
+        __syncthreads();
+    }
     // Visibility inside the workgroup: every mutable word is read and written with atomics or L1-bypassing loads, plain
     // stores (frontier lists, increments) are complete at the next __syncthreads() -- no agent-scope fence is needed
     // (three __threadfence() per level cost more than the level's work on small frontiers).
@@ -920,19 +955,21 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
         if (tid == 0) {
             s_count = __atomic_load_n(&d.fl_count[par][q * CSTRIDE], __ATOMIC_RELAXED);
             s_next = 0;
+            s_nwait = 0;
             s_dang = 0;
         }
         __syncthreads();
-        const uint32_t count = s_count;
-        if (!count) break;
+        const uint32_t count = s_count, real = s_real, ndue = s_ndue;
+        if (!real && !ndue) break;
         if (L >= MAX_LEVELS) { if (tid == 0) atomicOr(d.err, ERR_WL_OVERFLOW); break; }
         const uint32_t *in = d.fl[par] + slab;
         uint32_t *out = d.fl[par ^ 1] + slab;
         // ---- all pops of the level (algo.h:983-1002).  The entries of level L0 carry the residue already taken from
         // their nodes (see k_accum); later levels are collected by this kernel and take it here.
-        levels_run++;
+        if (real) levels_run++;
         for (uint32_t i = tid; i < count; i += TAIL_THREADS) {
             const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
+            if (v & HOLE) continue;
             const uint64_t a = slab + v;
             const uint64_t r = done ? atomicExch((unsigned long long *)&d.residue[a], 0ull)      // algo.h:984-985
                                     : __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
@@ -954,12 +991,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
             uint32_t cnt = 0;
             if (i < count) {
                 const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
-                int64_t beg; uint64_t deg;
-                node_row(d, v, beg, deg);
-                s_ebeg[tid] = beg;
-                const uint64_t inc = __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
-                s_inc[tid] = inc;
-                cnt = inc ? (uint32_t)deg : 0u;
+                if (!(v & HOLE)) {
+                    int64_t beg; uint64_t deg;
+                    node_row(d, v, beg, deg);
+                    s_ebeg[tid] = beg;
+                    const uint64_t inc = __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
+                    s_inc[tid] = inc;
+                    cnt = inc ? (uint32_t)deg : 0u;
+                }
             }
             uint32_t wtot;
             const uint32_t wx = wave_excl_scan(cnt, wtot);
@@ -1026,9 +1065,32 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
             }
         }
         __syncthreads();
+        uint32_t crossed = min(s_next, (uint32_t)d.n);
+        if (dk) {
+            // bounded deferral (see Dev::dbm): every add of the level has landed; a node that only just crossed becomes a
+            // hole in the next list and waits in dl[par ^ 1]; the nodes that waited since the previous level join the list
+            uint32_t *wait = d.dl[par ^ 1] + slab;
+            const uint32_t *due = d.dl[par] + slab;
+            for (uint32_t i = tid; i < crossed; i += TAIL_THREADS) {
+                const uint32_t w = out[i];
+                const uint64_t r = __atomic_load_n(&d.residue[slab + w], __ATOMIC_RELAXED);
+                if ((r >> dk) < node_thr(d.t1, d.deg[w])) {
+                    out[i] = w | HOLE;
+                    wait[atomicAdd(&s_nwait, 1u)] = w;
+                }
+            }
+            for (uint32_t i = tid; i < ndue; i += TAIL_THREADS) {
+                const uint32_t pos = crossed + i;
+                if (pos < (uint32_t)d.n) out[pos] = __atomic_load_n(&due[i], __ATOMIC_RELAXED); else atomicOr(d.err, ERR_WL_OVERFLOW);
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
-            d.fl_count[par ^ 1][q * CSTRIDE] = s_next;
+            const uint32_t nwait = dk ? s_nwait : 0u;
+            d.fl_count[par ^ 1][q * CSTRIDE] = min(crossed + (dk ? ndue : 0u), (uint32_t)d.n);
             d.fl_count[par][q * CSTRIDE] = 0;
+            s_real = crossed - nwait + (dk ? ndue : 0u);
+            s_ndue = nwait;
         }
         __syncthreads();
     }
@@ -1063,7 +1125,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     __shared__ uint32_t s_gbase;
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
     __shared__ uint32_t s_nlist;
-    __shared__ uint32_t s_scnt[MAX_SUB], s_total, s_ovn;
+    __shared__ uint32_t s_scnt[MAX_SUB], s_total, s_ovn, s_din, s_ndef;
     const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
     const int b = d.bin_lo + lb;
     const int par = L & 1;
@@ -1091,6 +1153,12 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
                 if (o > d.ov_cap) o = d.ov_cap;
             }
             s_ovn = o;
+            uint32_t di = 0;
+            if (!TO_PPR && d.defer_k) { // nodes of this bin deferred by the previous level: they are due now
+                di = d.dflag[par][(uint64_t)q * d.nbins + b];
+                if (di) d.dflag[par][(uint64_t)q * d.nbins + b] = 0;
+            }
+            s_din = di; s_ndef = 0;
         }
     }
     const uint32_t s = (uint32_t)d.src[q];
@@ -1101,7 +1169,12 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const uint32_t cnt = s_total;
     if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
     const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
-    if (cnt == 0 && dm == 0 && ovn == 0) return;
+    const bool din = !TO_PPR && s_din != 0;
+    if (cnt == 0 && dm == 0 && ovn == 0 && !din) return;
+    const int dk = TO_PPR ? 0 : d.defer_k;
+    const uint32_t wpb = BSZ / 64; // bitmap words per bin
+    uint64_t *dbm_in = TO_PPR ? nullptr : d.dbm[par] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
+    uint64_t *dbm_out = TO_PPR ? nullptr : d.dbm[par ^ 1] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
     uint32_t *fl_next = d.fl[par ^ 1] + slab;
     uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
     uint32_t *flc_next = &d.fl_count[par ^ 1][q * CSTRIDE];
@@ -1115,7 +1188,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const bool gather = !TO_PPR && !WIDE;
     const bool packed = !gather;
     const int pshift = WIDE ? BS : WPACK_SHIFT;
-    if (ovn == 0 && cnt + (dm ? 1 : 0) <= d.tiny_max) {
+    if (ovn == 0 && !din && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
         // node range and the level's pops are done, so nothing else touches these words).  Wave w takes sub-buckets
         // w, w + NW, ...
@@ -1161,10 +1234,44 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         __syncthreads(); // every add of this bucket has returned: the crossing nodes' residues are final
         const uint32_t nl = s_nlist;
         if (!nl) return;
-        if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, nl);
+        if (!dk) {
+            if (threadIdx.x == 0) s_gbase = atomicAdd(flc_next, nl);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nl; i += AT) {
+                const uint32_t w = s_list[i];
+                const uint64_t r = atomicExch((unsigned long long *)&d.residue[slab + w], 0ull); // algo.h:984-985
+                const uint32_t pos = s_gbase + i;
+                if (pos < (uint32_t)d.n) { fl_next[pos] = w; inc_next[pos] = r; }
+                else atomicOr(d.err, ERR_WL_OVERFLOW);
+            }
+            return;
+        }
+        // bounded deferral: a node that only just crossed keeps its residue and is marked for the next accumulate
+        // (acc[] is idle on this path: acc[0 .. 1023] collects the entries that do go to the frontier)
+        if (threadIdx.x == 0) s_total = 0;
         __syncthreads();
+        uint32_t ndef = 0;
         for (uint32_t i = threadIdx.x; i < nl; i += AT) {
             const uint32_t w = s_list[i];
+            const uint64_t r = __atomic_load_n(&d.residue[slab + w], __ATOMIC_RELAXED);
+            if ((r >> dk) < node_thr(t1q, d.deg[w])) {
+                atomicOr((unsigned long long *)&dbm_out[(w - node0) >> 6], 1ull << (w & 63u));
+                ndef++;
+            } else {
+                const uint32_t at = atomicAdd(&s_total, 1u);
+                acc[at] = ((uint64_t)w << 32); // node; the residue is taken below
+            }
+        }
+        if (ndef) atomicAdd(&s_ndef, ndef);
+        __syncthreads();
+        const uint32_t nf = s_total;
+        if (threadIdx.x == 0) {
+            if (nf) s_gbase = atomicAdd(flc_next, nf);
+            if (s_ndef) { d.dflag[par ^ 1][(uint64_t)q * d.nbins + b] = 1; atomicAdd(flc_next + 2, s_ndef); }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nf; i += AT) {
+            const uint32_t w = (uint32_t)(acc[i] >> 32);
             const uint64_t r = atomicExch((unsigned long long *)&d.residue[slab + w], 0ull); // algo.h:984-985
             const uint32_t pos = s_gbase + i;
             if (pos < (uint32_t)d.n) { fl_next[pos] = w; inc_next[pos] = r; }
@@ -1237,31 +1344,57 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
             STAMP_FLUSH(16);
             return;
         }
+        uint32_t duemask = 0; // bit k: node k * AT + thread was deferred by the previous level
+        if (din) {
+#pragma unroll
+            for (int k = 0; k < SWEEP; k++) { // one word per (k, wave): wave-uniform address
+                const uint64_t wd = dbm_in[(k * AT + wid * 64) >> 6];
+                if (wd) {
+                    duemask |= (uint32_t)((wd >> lane) & 1ull) << k;
+                    if (lane == 0) dbm_in[(k * AT + wid * 64) >> 6] = 0; // consumed
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
             old[k] = 0; dg[k] = 0;
-            if (v[k]) {
+            if (v[k] || ((duemask >> k) & 1u)) {
                 const uint32_t node = node0 + k * AT + threadIdx.x;
                 old[k] = target[slab + node];
                 if (!TO_PPR) dg[k] = d.deg[node];
             }
         }
         const bool pop = !TO_PPR && d.pop_next;
+        uint32_t defmask = 0; // bit k: the node crossed but waits a level
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
             const uint32_t node = node0 + k * AT + threadIdx.x;
-            if (v[k]) {
+            const bool due = (duemask >> k) & 1u;
+            if (v[k] || due) {
                 const uint64_t nw = old[k] + v[k];
                 bool cross = false;
                 if (!TO_PPR) {
                     const uint64_t thr = node_thr(t1q, dg[k]);
-                    cross = pop && old[k] < thr && nw >= thr; // algo.h:1012
+                    cross = pop && (due || (old[k] < thr && nw >= thr)); // algo.h:1012
+                    if (cross && !due && dk && (nw >> dk) < thr) { cross = false; defmask |= 1u << k; }
                 }
                 // this workgroup owns [node0, node0 + BSZ) of slot q; a crossing node gives its residue to the
                 // frontier entry written below (algo.h:984-985)
-                target[slab + node] = cross ? 0 : nw;
+                if (v[k] || cross) target[slab + node] = cross ? 0 : nw;
                 if (cross) { crossmask |= 1u << k; acc[k * AT + threadIdx.x] = nw; } // own LDS word: no barrier needed
             }
+        }
+        if (dk) { // marks for the next accumulate: one word per (k, wave), written by its only owner
+            uint32_t nd = 0;
+#pragma unroll
+            for (int k = 0; k < SWEEP; k++) {
+                const unsigned long long m = __ballot((defmask >> k) & 1u);
+                if (m) {
+                    if (lane == 0) dbm_out[(k * AT + wid * 64) >> 6] = m;
+                    nd += (uint32_t)__popcll(m);
+                }
+            }
+            if (nd && lane == 0) atomicAdd(&s_ndef, nd);
         }
     }
     STAMP(18);
@@ -1286,6 +1419,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         if (lane == 0) {
             s_rank[CELLS] = tot;
             s_gbase = tot ? atomicAdd(flc_next, tot) : 0u; // ONE global atomic per workgroup (the per-slot counter is a hot address)
+            if (dk && s_ndef) { d.dflag[par ^ 1][(uint64_t)q * d.nbins + b] = 1; atomicAdd(flc_next + 2, s_ndef); } // (the adds to s_ndef are behind the barrier above)
         }
     }
     __syncthreads();
@@ -2044,8 +2178,8 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     __shared__ uint32_t s_msg[BINNED ? CHUNK : 1];
     __shared__ uint16_t s_bin[BINNED ? CHUNK : 1];
     const int q = blockIdx.y;
-    const uint32_t nitems = d.wit_count[q * CSTRIDE];
-    if (!nitems) return;
+    const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (a reservation that did not fit set ERR_WIT_OVERFLOW and wrote nothing)
+    if (!nitems || *d.err) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t sub = d.sub; // BINNED: == gridDim.x, this workgroup owns sub-bucket blockIdx.x of every bin of the slot
@@ -2180,8 +2314,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
     __shared__ uint64_t s_j0[BLOCK], s_pos[BLOCK], s_incr[BLOCK], s_rem[BLOCK];
     __shared__ uint32_t s_v[BLOCK], s_idxn[BLOCK], s_pref[BLOCK + 1], s_w[4];
     const int q = blockIdx.y;
-    const uint32_t nitems = d.wit_count[q * CSTRIDE];
-    if (!nitems) return;
+    const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
+    if (!nitems || *d.err) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t stream = MODE == WALK_TO_INDEX ? 0xFFFFFFFFu : (uint32_t)d.src[q];
@@ -2338,8 +2472,8 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ uint64_t s_j0[DG_TILE], s_incr[DG_TILE], s_rem[DG_TILE];
     __shared__ uint32_t s_v[DG_TILE], s_vp[DG_TILE], s_idxn[DG_TILE], s_pref[DG_TILE + 1], s_w[NW];
     const int q = blockIdx.y;
-    const uint32_t nitems = d.wit_count[q * CSTRIDE];
-    if (!nitems) return;
+    const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
+    if (!nitems || *d.err) return;
     const WalkDG &g = d.dg;
     const uint32_t H = g.H, ts = g.ts;
     unsigned long long *s_hub = (unsigned long long *)dg_lds64;

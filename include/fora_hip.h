@@ -134,7 +134,12 @@ int fora_hip_set_batch(fora_ctx *ctx, int batch);
 int fora_hip_get_batch(fora_ctx *ctx);
 /* Engine knobs (layout choice, launch shapes, capacities; the list is `OPTIONS` in fora_hip.hip).  Every knob is read
  * once, in fora_hip_create, from the environment variable FORA_HIP_<NAME>; this call changes one afterwards (tests
- * use it to force the wide layout, tiny buckets, the k_push_tail path ...).  No knob changes a result bit.
+ * use it to force the wide layout, tiny buckets, the k_push_tail path ...).  Layout, capacity and launch-shape knobs
+ * change no result bit.  Three knobs choose another push SCHEDULE and with it other (equally valid) residue / reserve
+ * / ppr bits: "rounds" and "round_div" (threshold rounds) and "defer" (bounded deferral); all are off by default, and a
+ * run with them equals oracle/fora_twin.c run with the same values (orc_twin_set_rounds / _round_div / _defer).  A stray
+ * FORA_HIP_ROUNDS / FORA_HIP_DEFER in the environment therefore changes results: fora_query_stats.levels and .relax
+ * show it, and set_option("reset") followed by explicit values rules it out.
  * name "reset": back to the values fora_hip_create read.  Unknown name: FORA_E_ARG. */
 int fora_hip_set_option(fora_ctx *ctx, const char *name, int64_t value);
 

@@ -133,6 +133,8 @@ typedef struct {
 } orc_twin_push_stats;
 /* residue, ppr: n u64, zeroed by the callee.  level_sizes (optional, cap entries). */
 /* threshold rounds of orc_twin_push / orc_twin_query (the engine's option "rounds"; default 1) */
+void orc_twin_set_defer(int k); /* bounded deferral of the push (the engine's option "defer"; default 0: plain levels) */
+int orc_twin_get_defer(void);
 void orc_twin_set_rounds(int rounds);
 int orc_twin_get_rounds(void);
 void orc_twin_set_round_div(int div); /* 0 (default): a round ends when its frontier is empty */

@@ -273,6 +273,15 @@ def twin_walk_counts(g, residue, rsum_fix, omega, alpha=0.2, opt=False):
     return N, out
 
 
+def twin_set_defer(k):
+    """Bounded deferral of the twin's push (the engine's option \"defer\"; default 0: plain levels)."""
+    lib().orc_twin_set_defer(C.c_int(int(k)))
+
+
+def twin_get_defer():
+    return int(lib().orc_twin_get_defer())
+
+
 def twin_set_rounds(rounds):
     """Threshold rounds of the twin's push (the engine's option \"rounds\", default 1)."""
     lib().orc_twin_set_rounds(C.c_int(int(rounds)))

@@ -417,6 +417,53 @@ def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds, div)
         oracle.twin_set_round_div(0)
 
 
+@pytest.mark.parametrize("layout", ["narrow", "wide", "wide_multipass", "tail"])
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, layout):
+    """Bounded deferral of the push (option "defer", Dev::defer_k): a node that crosses with less than 2^k x its
+    threshold waits one level.  Every k equals the twin running the same schedule bit for bit -- in the bitmap form of
+    the bucketed levels, the list form of k_push_tail and across the hand-over between them -- ends with the exit
+    condition of algo.h:1012, conserves mass exactly, and k = 1 relaxes fewer edges and leaves less residue than plain
+    levels (k = 0, the default: the extra levels cost more on the GPU than the edges save)."""
+    g = small_dangling
+    if layout in ("wide", "wide_multipass"):
+        engine.set_option("force_wide", 1)
+    if layout == "wide_multipass":
+        engine.set_option("pass_bins", 1)
+    if layout == "tail":
+        engine.set_option("tail", 100000000)
+        engine.set_option("tail_always", 1)
+    else:
+        engine.set_option("tail", 64)  # most levels bucketed, the small ones by k_push_tail: the hand-over is exercised
+    rmax, omega = _load(engine, g, epsilon=0.5)
+    srcs = np.concatenate([pick_sources(g, 6, 81), pick_sources(g, 1, 82, want_dangling=True)])
+    try:
+        engine.set_option("defer", 0)
+        _, _, st0 = engine.push(srcs)
+        engine.set_option("defer", k)
+        oracle.twin_set_defer(k)
+        rsv, res, st = engine.push(srcs)
+        t1 = int(np.ceil(np.ldexp(rmax, 62)))
+        for i, s in enumerate(srcs):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+            assert int(rsv[i].sum()) + int(res[i].sum()) == oracle.FIX_ONE
+            thr = (t1 * g.deg).astype(np.uint64)
+            thr[g.deg == 0] = 1
+            assert (res[i] < thr).all()
+        if k == 1:
+            assert sum(int(x["relax"]) for x in st) < sum(int(x["relax"]) for x in st0)
+            assert sum(int(x["rsum_fix"]) for x in st) < sum(int(x["rsum_fix"]) for x in st0)
+        ppr, _, stq = engine.query_fix(srcs[:3], want_residue=False)
+        for i in range(3):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+            assert (ppr[i] == want).all() and stq[i]["n_walks"] == wst["n_walks"]
+    finally:
+        engine.reset_options()
+        oracle.twin_set_defer(0)
+
+
 def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):
     """Opt-in second lane (push of batch k+1 overlapping walks of batch k) gives the same bits."""
     g = small
