@@ -58,6 +58,7 @@ def parse(argv=None):
                     help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --balanced timing")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the L-inf check against exact PPR")
+    ap.add_argument("--no-configs", action="store_true", help="default run only: skip the brief measurements of BASELINE configs 3-5")
     ap.add_argument("--topk", type=int, default=0, help="k > 0: time `topk --opt` (config 5 style) instead of `query`")
     ap.add_argument("--traffic", default="", help="per-kernel FETCH_SIZE/WRITE_SIZE summary from separate rocprofv3 --pmc passes "
                                                   "(tools/pmc_summary.py); default profiles/pmc_traffic_<graph>[_idx].json")
@@ -177,7 +178,7 @@ def plumbing_only(args):
     import numpy as np
     import torch.distributed as dist
     from fora_amd import synth
-    from fora_amd.dist import env_world, max_over_ranks, sum_over_ranks, gather_topk
+    from fora_amd.dist import env_world, max_over_ranks, min_over_ranks, sum_over_ranks, gather_topk
     rank, _, world = env_world()
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if use_dist:
@@ -203,57 +204,66 @@ def plumbing_only(args):
         step()
     if use_dist:
         dist.barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, world if use_dist else 1)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, world if use_dist else 1)
     tot = sum_over_ranks([len(mine)], world if use_dist else 1)
+    my_qps = len(mine) * args.steps / dt_local
+    ranks = {"world_size_seen": int(dist.get_world_size()) if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+             "rccl": bool(use_dist and dist.get_backend() == "nccl"),
+             "per_rank_queries_per_s": {"min": min_over_ranks(my_qps, world if use_dist else 1),
+                                        "max": max_over_ranks(my_qps, world if use_dist else 1)}}
     ok = bool((g_ids[:, 0] == all_sources).all())
     if rank == 0:
         print(json.dumps({"metric": "plumbing-only", "value": tot[0] * args.steps / dt, "unit": "queries/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": args.scaling, "queries_total_per_step": int(tot[0]),
-                          "gather_in_global_order": ok}))
+                          "gather_in_global_order": ok, "ranks": ranks}))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1
 
 
-def main():
-    args = parse()
-    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # started by torch.distributed.run
-    if args.gpus > 1 and not under_launcher:
-        return launch(args)
-    if under_launcher and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}", file=sys.stderr)
-        return 2
-    if args.plumbing_only:
-        return plumbing_only(args)
-    import torch  # first: the process must use ONE HIP runtime (torch's), the library binds to it
-    import torch.distributed as dist
-    import numpy as np
+def fifo_ratio_file(graph):
+    """FIFO / GPU-schedule work ratios of a graph measured once in a builder run (profiles/fifo_counts_<graph>.json,
+    tools/fifo_counts.py): one sequential FIFO push of a Twitter-2010-sized source is about a minute of one core, too
+    long for the default bench run.  Returns (pop ratio, relaxation ratio, note) or None."""
+    path = os.path.join(ROOT, "profiles", f"fifo_counts_{graph}.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d["fifo_pops"] / d["gpu_pops"], d["fifo_relax"] / d["gpu_relax"], d.get("note", path)
+
+
+def run_workload(args, ctx, light=False):
+    """One workload: graph, engine, warm-up, timed steps, the result object (rank 0; None on the others).
+    light: an extra configuration inside the default run -- no CPU legs, no accuracy pass, no variants."""
+    torch, dist, np = ctx["torch"], ctx["dist"], ctx["np"]
     import fora_amd
     from fora_amd import synth
-    from fora_amd.dist import env_world, max_over_ranks, sum_over_ranks, gather_topk
+    from fora_amd.dist import max_over_ranks, min_over_ranks, sum_over_ranks, gather_topk
+    rank, local_rank, world, use_dist, dev = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["use_dist"], ctx["dev"]
 
-    rank, local_rank, world = env_world()
-    use_dist = under_launcher
-    torch.cuda.set_device(local_rank)
-    if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
-        assert dist.get_world_size() == args.gpus
-    dev = torch.device("cuda", local_rank)
-
-    t0 = time.perf_counter()
-    n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
-    t_graph = time.perf_counter() - t0
-    eng = fora_amd.Engine(local_rank)
+    cache = ctx.setdefault("cache", {})
+    key = (args.graph, args.dangling)
+    t_graph = t_upload = 0.0
+    if key in cache:
+        n, m, row_ptr, col, eng = cache[key]
+    else:
+        for k_old in list(cache):  # one graph at a time in HBM and in host memory
+            cache.pop(k_old)[4].close()
+        t0 = time.perf_counter()
+        n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
+        t_graph = time.perf_counter() - t0
+        eng = fora_amd.Engine(local_rank)
+        t0 = time.perf_counter()
+        eng.set_graph(n, m, row_ptr, col)
+        t_upload = time.perf_counter() - t0
+        cache[key] = (n, m, row_ptr, col, eng)
     arch, cus, hbm = eng.device_info()
-    t0 = time.perf_counter()
-    eng.set_graph(n, m, row_ptr, col)
-    t_upload = time.perf_counter() - t0
     eng.set_params(alpha=0.2, epsilon=args.epsilon, opt=args.opt or bool(args.topk), seed=0x464F5241)
     rmax, omega = eng.get_params()
-    if args.batch:
-        eng.set_batch(args.batch)
+    eng.set_batch(args.batch)
     if args.balanced:
         eng.set_balanced(True, start_scale=args.balanced_start)
     t_idx = 0.0
@@ -261,6 +271,8 @@ def main():
         t0 = time.perf_counter()
         eng.build_index()
         t_idx = time.perf_counter() - t0
+    else:
+        eng.clear_index()
 
     all_sources, mine = my_sources(np, synth, n, args, rank, world)
     q_step_total = len(all_sources)
@@ -290,183 +302,306 @@ def main():
     for _ in range(args.steps):
         last = step()
     fence()
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, world if use_dist else 1, dev)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, world if use_dist else 1, dev)
     tm = eng.timing()
     shard = f"sources i mod {world}"
     qdesc = (f"query_size={args.queries}/GPU" if args.scaling == "weak" else f"query_size={args.queries} in total ({shard})")
+    # evidence of the N > 1 run in the line itself: what torch.distributed saw, and the spread over the ranks
+    my_qps = len(mine) * args.steps / dt_local
+    ranks = {"world_size_seen": int(dist.get_world_size()) if use_dist else 1,
+             "backend": (dist.get_backend() if use_dist else None),
+             "rccl": bool(use_dist and dist.get_backend() == "nccl"),
+             "per_rank_queries_per_s": {"min": min_over_ranks(my_qps, world if use_dist else 1, dev),
+                                        "max": max_over_ranks(my_qps, world if use_dist else 1, dev)},
+             "timing": "barrier + torch.cuda.synchronize() on both sides of the K steps, MAX over ranks"}
+    setup = {"graph": t_graph, "upload": t_upload, "index_build": t_idx}
 
     if args.topk:
         g_sc = topk_out["sc"]
         assert g_sc.shape == (q_step_total, args.topk)
         assert (np.diff(g_sc, axis=1) <= 0).all()
         rounds_all = sum_over_ranks([float(np.sum(topk_out["rounds"])), float(len(mine))], world if use_dist else 1, dev)
-        if rank == 0:
-            print(json.dumps({
-                "metric": "SSPPR top-k queries/sec at eps=0.5", "value": q_step_total * args.steps / dt,
-                "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-                "dtype": DTYPE, "data": "synthetic",
-                "config": {"workload": f"{args.graph}-sized R-MAT (n={n}, m={m}) topk k={args.topk} --opt"
-                                       f"{' --with_idx' if args.with_idx else ''} eps={args.epsilon} {qdesc} on {world}x MI355X, "
-                                       f"RCCL all-gather of the [Q, k] lists inside the timed region",
-                           "graph": args.graph, "n": n, "m": m, "k": args.topk, "avg_rounds": rounds_all[0] / max(1.0, rounds_all[1]),
-                           "batch": eng.get_batch(), "sharding": shard, "device": arch, "cus": cus,
-                           "gather_bytes_per_step": int(q_step_total * args.topk * 12)},
-                "phases": {k: v for k, v in tm.items() if k.endswith("_ms")},
-                "setup_s": {"graph": t_graph, "upload": t_upload, "index_build": t_idx}}))
-        eng.close()
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
-        return 0
+        if rank != 0:
+            return None
+        return {
+            "metric": "SSPPR top-k queries/sec at eps=0.5", "value": q_step_total * args.steps / dt,
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": f"{args.graph}-sized R-MAT (n={n}, m={m}) topk k={args.topk} --opt"
+                                   f"{' --with_idx' if args.with_idx else ''} eps={args.epsilon} {qdesc} on {world}x MI355X, "
+                                   f"RCCL all-gather of the [Q, k] lists inside the timed region",
+                       "graph": args.graph, "n": n, "m": m, "k": args.topk, "avg_rounds": rounds_all[0] / max(1.0, rounds_all[1]),
+                       "queries_per_step": int(q_step_total),
+                       "batch": eng.get_batch(), "sharding": shard, "device": arch, "cus": cus,
+                       "gather_bytes_per_step": int(q_step_total * args.topk * 12)},
+            "ranks": ranks,
+            "phases": {k: v for k, v in tm.items() if k.endswith("_ms")},
+            "setup_s": setup}
     # sanity inside the bench: every query conserved mass exactly, none was skipped
     assert len(last) == len(mine)
     assert all(s["ppr_sum_fix"] == 1 << 62 for s in last), "mass not conserved"
     nd = sum(1 for s in last if not s["dangling_source"])
     tot = sum_over_ranks([len(mine), nd, tm["walks"], tm["walk_steps"], tm["relax"], tm["pops"]],
                          world if use_dist else 1, dev)
-
-    if rank == 0:
-        qps = tot[0] * args.steps / dt
-        out = {
-            "metric": "SSPPR queries/sec at eps=0.5", "value": qps, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {
-                "workload": f"{args.graph}-sized R-MAT (n={n}, m={m}, dangling={args.dangling}) eps={args.epsilon} "
-                            f"{qdesc}, fora push + "
-                            f"{'indexed' if args.with_idx else 'online Philox'} walks"
-                            f"{' --opt' if args.opt else ''}{' --balanced' if args.balanced else ''} on {world}x MI355X",
-                "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "queries_per_step": int(tot[0]),
-                "with_idx": bool(args.with_idx), "opt": bool(args.opt), "balanced": bool(args.balanced), "batch": eng.get_batch(),
-                "sharding": shard, "non_dangling_sources": int(tot[1]),
-                "rmax": rmax, "omega": omega, "device": arch, "cus": cus,
-            },
-        }
-        q_timed = len(mine) * args.steps  # queries this rank ran in the timed region
-        p_fifo = e_fifo = None
-        counts_from = "GPU schedule (no CPU sample)"
-        g = None
-        if not args.no_cpu:
+    if rank != 0:
+        return None
+    qps = tot[0] * args.steps / dt
+    out = {
+        "metric": "SSPPR queries/sec at eps=0.5", "value": qps, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {
+            "workload": f"{args.graph}-sized R-MAT (n={n}, m={m}, dangling={args.dangling}) eps={args.epsilon} "
+                        f"{qdesc}, fora push + "
+                        f"{'indexed' if args.with_idx else 'online Philox'} walks"
+                        f"{' --opt' if args.opt else ''}{' --balanced' if args.balanced else ''} on {world}x MI355X",
+            "graph": args.graph, "n": n, "m": m, "epsilon": args.epsilon, "queries_per_step": int(tot[0]),
+            "with_idx": bool(args.with_idx), "opt": bool(args.opt), "balanced": bool(args.balanced), "batch": eng.get_batch(),
+            "sharding": shard, "non_dangling_sources": int(tot[1]),
+            "rmax": rmax, "omega": omega, "device": arch, "cus": cus,
+        },
+        "ranks": ranks,
+    }
+    q_timed = len(mine) * args.steps  # queries this rank ran in the timed region
+    p_fifo = e_fifo = None
+    counts_from = "GPU schedule (no CPU sample)"
+    g = None
+    if not args.no_cpu:
+        import oracle_lib as O
+        per_query_guess = 0.05e-6 * m  # one oracle query: LJ-sized 3.4 s, Twitter-sized about 75 s of one core
+        if not light and world == 1 and per_query_guess <= args.cpu_seconds:  # the CPU baseline is timed at N = 1 only
+            g = O.Graph(n, m, row_ptr, col)
+            index = None
+            if args.with_idx:
+                rw, off, cnt = eng.get_index()
+                index = (rw, off, cnt)
+            cpu, p_fifo, e_fifo = cpu_baseline(g, mine, rmax, omega, args, index)
+            counts_from = "sequential FIFO oracle (CPU), same sources"
+            out["cpu_baseline"] = cpu
+            threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
+            if threads > 1 and cpu["value"] * args.cpu_seconds >= 10:  # every thread runs at least one whole query: only when one fits the budget ten times over
+                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
+        elif per_query_guess <= 5.0:  # N > 1 or an extra configuration: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
+            g = O.Graph(n, m, row_ptr, col)
+            t1 = time.perf_counter()
+            pp = pr = pn = 0
+            for s in mine[:64]:
+                ps = O.push_fifo(g, int(s), rmax)
+                pp += ps["pops"]; pr += ps["relax"]; pn += 1
+                if time.perf_counter() - t1 > 5.0:
+                    break
+            p_fifo, e_fifo = pp / max(1, pn), pr / max(1, pn)
+            counts_from = f"sequential FIFO oracle (CPU), first {pn} of the same sources"
+            if world > 1:
+                out["cpu_baseline"] = None
+                out["cpu_baseline_note"] = "the CPU port is timed at N = 1 only (default `python bench.py`)"
+        else:
+            fr = fifo_ratio_file(args.graph)
+            if fr:
+                p_fifo = fr[0] * tm["pops"] / max(1, q_timed)
+                e_fifo = fr[1] * tm["relax"] / max(1, q_timed)
+                counts_from = f"GPU schedule counts x FIFO/GPU ratios (pops {fr[0]:.3f}, relaxations {fr[1]:.3f}) of a builder run: {fr[2]}"
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = (f"one oracle query on this graph needs about {per_query_guess:.0f} s of one core, more than "
+                                        f"--cpu-seconds {args.cpu_seconds:g}; raise it to time the CPU port here")
+    if not light and not args.no_accuracy and not args.opt:
+        if g is None and not args.no_cpu and m <= 200_000_000:
             import oracle_lib as O
             g = O.Graph(n, m, row_ptr, col)
-            per_query_guess = 0.05e-6 * m  # one oracle query: LJ-sized 3.4 s, Twitter-sized about 75 s of one core
-            if world == 1 and per_query_guess <= args.cpu_seconds:  # the CPU baseline is timed at N = 1 only
-                index = None
-                if args.with_idx:
-                    rw, off, cnt = eng.get_index()
-                    index = (rw, off, cnt)
-                cpu, p_fifo, e_fifo = cpu_baseline(g, mine, rmax, omega, args, index)
-                counts_from = "sequential FIFO oracle (CPU), same sources"
-                out["cpu_baseline"] = cpu
-                threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
-                if threads > 1 and cpu["value"] * args.cpu_seconds >= 10:  # every thread runs at least one whole query: only when one fits the budget ten times over
-                    out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
-            elif per_query_guess <= 5.0:  # N > 1: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
-                t1 = time.perf_counter()
-                pp = pr = pn = 0
-                for s in mine[:64]:
-                    ps = O.push_fifo(g, int(s), rmax)
-                    pp += ps["pops"]; pr += ps["relax"]; pn += 1
-                    if time.perf_counter() - t1 > 5.0:
-                        break
-                p_fifo, e_fifo = pp / max(1, pn), pr / max(1, pn)
-                counts_from = "sequential FIFO oracle (CPU), same sources"
-            else:
-                out["cpu_baseline"] = None
-                out["cpu_baseline_note"] = (f"one oracle query on this graph needs about {per_query_guess:.0f} s of one core, more than "
-                                            f"--cpu-seconds {args.cpu_seconds:g}; raise it to time the CPU port here")
-        if not args.no_accuracy and not args.opt:
-            out["accuracy"] = accuracy(eng, g, mine, n, m, args, np)
-        if world == 1 and not args.balanced and not args.no_variants and args.graph in ("webstanford", "small", "tiny"):
-            # the reference's other way to run the same query path (README.md:135): --balanced; not the headline value
-            eng.set_balanced(True, start_scale=args.balanced_start)
-            eng.query(mine, with_idx=args.with_idx, want_ppr=False)
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(args.steps):
-                _, stb = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
-            torch.cuda.synchronize()
-            dtb = time.perf_counter() - tb
-            eng.set_balanced(False)
-            assert all(s["ppr_sum_fix"] == 1 << 62 for s in stb)
-            out["variants"] = {"balanced": {
-                "value": len(mine) * args.steps / dtb, "unit": "queries/s",
-                "mean_rmax_ratio": float(np.mean([s["rmax_used"] / rmax for s in stb if not s["dangling_source"]])),
-                "walks_per_query": float(np.mean([s["n_walks"] for s in stb])),
-                "start_scale": args.balanced_start,
-                "note": "--balanced (query.h:848-884) with the MI355X cost model of fora_hip_set_balanced; same guarantee"}}
-        # roofline of the push kernels: ALGORITHMIC bytes = 52 B per pop + 24 B per edge relaxation of the
-        # sequential FIFO oracle; relaxations the level-synchronous schedule adds on top are
-        # not credited.  Duration: HIP events around every launch.
-        if tm["push_expand_launches"]:
-            e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
-            p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
-            launches = tm["push_expand_launches"] + tm["push_tail_launches"]  # bin-kernel launches (levels x passes) + the tail launch per batch
-            bucketed = tm["push_accum_launches"] > 0
-            # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
-            # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
-            # relaxation, credited once against the sum of both kernels' durations
-            alg_bytes = (24.0 * e_unit + (52.0 * p_unit if bucketed else 0.0)) * q_timed
-            step_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"]
-            avg_ms = step_ms / launches
-            achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            traffic_note = None
-            tpath = args.traffic or os.path.join(ROOT, "profiles", f"pmc_traffic_{args.graph}{'_idx' if args.with_idx else ''}.json")
-            if os.path.exists(tpath):
-                # HBM-side bytes per launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE and
-                # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
-                # coalesced reads by up to 2x on gfx950 -- these kernels read 4-12 B per lane, reported raw)
-                pmc = json.load(open(tpath))
-                prefixes = (["fora::k_pushq_bin", "fora::k_accum<false", "fora::k_push_tail"] if bucketed else ["fora::k_push_expand"])
-                keys = [k for k in pmc if any(k.startswith(p) for p in prefixes)]
-                lead = [k for k in pmc if k.startswith(prefixes[0])]
-                if lead and all("FETCH_SIZE_bytes_total" in pmc[k] for k in keys):
-                    # all push kernels of the profiled batch, per level launch (the unit `achieved` uses): the bin
-                    # kernel's launches plus the one k_push_tail that finishes the small levels
-                    n_launch = sum(pmc[k].get("FETCH_SIZE_dispatches", 0) for k in keys
-                                   if k.startswith(prefixes[0]) or k.startswith("fora::k_push_tail"))
-                    traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
-                                  for k in keys) / max(1, n_launch)
-                    traffic_note = pmc.get("_note")
-            by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / max(1, tm["push_expand_launches"])}
-            if bucketed:
-                by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
-            if tm["push_tail_launches"]:
-                by_kernel["k_push_tail"] = tm["push_tail_ms"] / tm["push_tail_launches"]
-            if tm["push_pop_launches"]:
-                by_kernel["k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": ("fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
-                           if bucketed else "fora::k_push_expand"),
-                "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
-                "algorithmic_bytes_per_launch": alg_bytes / launches,
-                "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation" if bucketed else "24 B per edge relaxation",
-                "algorithmic_counts": counts_from,
-                "fifo_relaxations_per_query": e_unit, "fifo_pops_per_query": p_unit,
-                "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed), "gpu_pops_per_query": tm["pops"] / max(1, q_timed),
-                "push_total": {  # all push kernels against 52*P + 24*E
-                    "achieved": (52.0 * p_unit + 24.0 * e_unit) * q_timed
-                                / ((step_ms + tm["push_pop_ms"]) * 1e-3) / 1e9,
-                    "ms": step_ms + tm["push_pop_ms"]},
-            }
-        walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
-        out["phases"] = {
-            "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
-            "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "walk_accum_ms": tm["walk_accum_ms"], "other_ms": tm["other_ms"],
-            "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
-            "walks": tm["walks"], "walk_steps": tm["walk_steps"],
-            "walks_per_s": tm["walks"] / max(1e-9, tm["walk_ms"] * 1e-3),
-            "walk_algorithmic_GBps": walk_bytes / max(1e-9, tm["walk_ms"] * 1e-3) / 1e9,
-            "index_build_s": t_idx, "graph_s": t_graph, "upload_s": t_upload,
+        out["accuracy"] = accuracy(eng, g, mine, n, m, args, np)
+    if not light and world == 1 and not args.balanced and not args.no_variants and args.graph in ("webstanford", "small", "tiny"):
+        # the reference's other way to run the same query path (README.md:135): --balanced; not the headline value
+        eng.set_balanced(True, start_scale=args.balanced_start)
+        eng.query(mine, with_idx=args.with_idx, want_ppr=False)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            _, stb = eng.query(mine, with_idx=args.with_idx, want_ppr=False)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb
+        eng.set_balanced(False)
+        assert all(s["ppr_sum_fix"] == 1 << 62 for s in stb)
+        out["variants"] = {"balanced": {
+            "value": len(mine) * args.steps / dtb, "unit": "queries/s",
+            "mean_rmax_ratio": float(np.mean([s["rmax_used"] / rmax for s in stb if not s["dangling_source"]])),
+            "walks_per_query": float(np.mean([s["n_walks"] for s in stb])),
+            "start_scale": args.balanced_start,
+            "note": "--balanced (query.h:848-884) with the MI355X cost model of fora_hip_set_balanced; same guarantee"}}
+    # roofline of the push kernels: ALGORITHMIC bytes = 52 B per pop + 24 B per edge relaxation of the
+    # sequential FIFO oracle; relaxations the level-synchronous schedule adds on top are
+    # not credited.  Duration: HIP events around every launch.
+    if tm["push_expand_launches"]:
+        e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
+        p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
+        launches = tm["push_expand_launches"] + tm["push_tail_launches"]  # bin-kernel launches (levels x passes) + the tail launch per batch
+        bucketed = tm["push_accum_launches"] > 0
+        # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
+        # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
+        # relaxation, credited once against the sum of both kernels' durations
+        alg_bytes = (24.0 * e_unit + (52.0 * p_unit if bucketed else 0.0)) * q_timed
+        step_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"]
+        avg_ms = step_ms / launches
+        achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        traffic_note = None
+        tpath = args.traffic or os.path.join(ROOT, "profiles", f"pmc_traffic_{args.graph}{'_idx' if args.with_idx else ''}.json")
+        if os.path.exists(tpath):
+            # HBM-side bytes per launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE and
+            # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
+            # coalesced reads by up to 2x on gfx950 -- calibration on known byte counts: profiles/r03_pmc_calibration.txt)
+            pmc = json.load(open(tpath))
+            prefixes = (["fora::k_pushq_bin", "fora::k_accum<false", "fora::k_push_tail"] if bucketed else ["fora::k_push_expand"])
+            keys = [k for k in pmc if any(k.startswith(p) for p in prefixes)]
+            lead = [k for k in pmc if k.startswith(prefixes[0])]
+            if lead and all("FETCH_SIZE_bytes_total" in pmc[k] for k in keys):
+                # all push kernels of the profiled batch, per level launch (the unit `achieved` uses): the bin
+                # kernel's launches plus the one k_push_tail that finishes the small levels
+                n_launch = sum(pmc[k].get("FETCH_SIZE_dispatches", 0) for k in keys
+                               if k.startswith(prefixes[0]) or k.startswith("fora::k_push_tail"))
+                traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
+                              for k in keys) / max(1, n_launch)
+                traffic_note = pmc.get("_note")
+        by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / max(1, tm["push_expand_launches"])}
+        if bucketed:
+            by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
+        if tm["push_tail_launches"]:
+            by_kernel["k_push_tail"] = tm["push_tail_ms"] / tm["push_tail_launches"]
+        if tm["push_pop_launches"]:
+            by_kernel["k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+            "kernel": ("fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
+                       if bucketed else "fora::k_push_expand"),
+            "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
+            "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation" if bucketed else "24 B per edge relaxation",
+            "algorithmic_counts": counts_from,
+            "fifo_relaxations_per_query": e_unit, "fifo_pops_per_query": p_unit,
+            "gpu_relaxations_per_query": tm["relax"] / max(1, q_timed), "gpu_pops_per_query": tm["pops"] / max(1, q_timed),
+            "push_total": {  # all push kernels against 52*P + 24*E
+                "achieved": (52.0 * p_unit + 24.0 * e_unit) * q_timed
+                            / ((step_ms + tm["push_pop_ms"]) * 1e-3) / 1e9,
+                "ms": step_ms + tm["push_pop_ms"]},
         }
+    walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
+    out["phases"] = {
+        "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
+        "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "walk_accum_ms": tm["walk_accum_ms"], "other_ms": tm["other_ms"],
+        "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
+        "walks": tm["walks"], "walk_steps": tm["walk_steps"],
+        "walks_per_s": tm["walks"] / max(1e-9, tm["walk_ms"] * 1e-3),
+        "walk_algorithmic_GBps": walk_bytes / max(1e-9, tm["walk_ms"] * 1e-3) / 1e9,
+        "index_build_s": t_idx, "graph_s": t_graph, "upload_s": t_upload,
+    }
+    return out
+
+
+# The other BASELINE.json configurations, measured briefly inside the default run (N = 1) so that the driver's
+# BENCH line carries them: config 3 (LiveJournal-sized --with_idx), config 4's one-GPU share (Twitter-2010-sized
+# --with_idx, 125 of the 1000 sources) and config 5's (top-k k=500 --opt --with_idx, 125 sources).
+EXTRA_CONFIGS = [
+    ("config3_livejournal_with_idx", dict(graph="livejournal", with_idx=True, queries=1000, steps=2, warmup=1)),
+    ("config4_twitter2010_with_idx_one_gpu_share", dict(graph="twitter2010", with_idx=True, queries=125, steps=1, warmup=1)),
+    ("config5_twitter2010_topk500_with_idx_one_gpu_share", dict(graph="twitter2010", with_idx=True, topk=500, queries=125, steps=2, warmup=1)),
+]
+
+
+def summarize(d):
+    """compact entry of an extra configuration"""
+    e = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+         "steps": d["steps"], "warmup": d["warmup"], "queries_per_step": d["config"].get("queries_per_step"),
+         "batch": d["config"].get("batch"), "setup_s": d.get("setup_s") or
+         {"graph": d["phases"]["graph_s"], "upload": d["phases"]["upload_s"], "index_build": d["phases"]["index_build_s"]}}
+    if "roofline" in d:
+        r = d["roofline"]
+        e["roofline"] = {k: r[k] for k in ("frac", "achieved", "peak", "unit", "kernel", "launches", "avg_launch_ms", "avg_ms_by_kernel",
+                                           "algorithmic_bytes", "algorithmic_counts", "fifo_relaxations_per_query",
+                                           "gpu_relaxations_per_query", "traffic")}
+    ph = d.get("phases", {})
+    e["phases_ms_per_step"] = {k: v / max(1, d["steps"]) for k, v in ph.items() if k.endswith("_ms")}
+    if "avg_rounds" in d["config"]:
+        e["avg_rounds"] = d["config"]["avg_rounds"]
+        e["k"] = d["config"]["k"]
+    return e
+
+
+def main():
+    args = parse()
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # started by torch.distributed.run
+    if args.gpus > 1 and not under_launcher:
+        return launch(args)
+    if under_launcher and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}", file=sys.stderr)
+        return 2
+    if args.plumbing_only:
+        return plumbing_only(args)
+    import torch  # first: the process must use ONE HIP runtime (torch's), the library binds to it
+    import torch.distributed as dist
+    import numpy as np
+    from fora_amd.dist import env_world
+
+    rank, local_rank, world = env_world()
+    use_dist = under_launcher
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
+    ctx = {"torch": torch, "dist": dist, "np": np, "rank": rank, "local_rank": local_rank, "world": world,
+           "use_dist": use_dist, "dev": torch.device("cuda", local_rank)}
+    out = run_workload(args, ctx)
+    # the default invocation (the driver's BENCH line) also measures the other BASELINE configurations, briefly
+    default_run = (world == 1 and args.graph == "webstanford" and args.dangling == "none" and not args.with_idx and not args.topk
+                   and not args.opt and not args.balanced and not args.batch and args.epsilon == 0.5 and not args.no_configs)
+    if default_run and out is not None:
+        import copy
+        t_extra = time.perf_counter()
+        if not args.no_variants:
+            # SURVEY 8d: the plain R-MAT graph (about 43 % of the nodes have no out-edge; dangling sources finish at once,
+            # dangling targets send their mass back to the source, algo.h:993-999): q/s over all and over the non-dangling sources
+            a = copy.copy(args); a.dangling = "rmat"; a.no_cpu = True; a.steps = 3; a.warmup = 1
+            try:
+                d_all = run_workload(a, ctx, light=True)
+                n_nd = d_all["config"]["non_dangling_sources"]
+                eng = ctx["cache"][("webstanford", "rmat")][4]
+                from fora_amd import synth
+                srcs = synth.query_set(d_all["config"]["n"], a.queries, 20261001)
+                _, st = eng.query(srcs, want_ppr=False)
+                nds = srcs[[i for i, x in enumerate(st) if not x["dangling_source"]]]
+                eng.query(nds, want_ppr=False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    eng.query(nds, want_ppr=False)
+                torch.cuda.synchronize()
+                dt_nd = time.perf_counter() - t0
+                out.setdefault("variants", {})["dangling_rmat"] = {
+                    "graph": d_all["config"]["workload"], "value_all_sources": d_all["value"],
+                    "value_non_dangling_sources": len(nds) * a.steps / dt_nd, "unit": "queries/s",
+                    "sources": int(a.queries), "non_dangling_sources": int(n_nd), "steps": a.steps,
+                    "roofline_frac_gpu_counts": d_all.get("roofline", {}).get("frac"),
+                    "phases_ms_per_step": {k: v / a.steps for k, v in d_all["phases"].items() if k.endswith("_ms")}}
+            except Exception as e:  # never lose the headline line to an extra
+                out.setdefault("variants", {})["dangling_rmat"] = {"error": repr(e)[:300]}
+        out["configs"] = {}
+        for name, over in EXTRA_CONFIGS:
+            a = copy.copy(args)
+            a.no_variants = True; a.no_accuracy = True
+            for k, v in over.items():
+                setattr(a, k, v)
+            try:
+                out["configs"][name] = summarize(run_workload(a, ctx, light=True))
+            except Exception as e:
+                out["configs"][name] = {"error": repr(e)[:300]}
+        out["configs"]["_note"] = ("BASELINE.json configs 3-5 measured inside this same run on 1 GPU, few steps each (the headline keys above are "
+                                   f"config 2); {time.perf_counter() - t_extra:.0f} s for all extras")
+    for k_old in list(ctx.get("cache", {})):
+        ctx["cache"].pop(k_old)[4].close()
+    if rank == 0 and out is not None:
         print(json.dumps(out))
-    eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

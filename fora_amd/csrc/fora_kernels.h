@@ -53,6 +53,15 @@ constexpr int ACC_THREADS = FORA_ACC_THREADS;
 #endif
 constexpr int ACC_THREADS_WIDE = FORA_ACC_THREADS_WIDE; // 16 nodes per lane in the sweep, as in the narrow layout (512 threads: accumulate 214 -> 265 ms on the LJ-sized graph)
 constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin / k_walk_idx
+// wide layouts: edges (index walks) per thread per chunk.  A chunk's messages are written out in one run per bin; with
+// hundreds to thousands of bins a run is a few messages -- partial-line writes (Twitter-2010-sized, 8 per thread:
+// 3.2 messages per run, WRITE_SIZE 1.77 x the payload) -- and twice the chunk is twice the run.
+#ifndef FORA_BIN_EPT_WIDE
+#define FORA_BIN_EPT_WIDE 12
+#endif
+#ifndef FORA_IDX_EPT_WIDE
+#define FORA_IDX_EPT_WIDE 12
+#endif
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 // bucket messages are read exactly once: non-temporal loads keep them from displacing the increment table and the
 // slabs in L2 (accumulate kernels -1 %)
@@ -691,6 +700,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     constexpr uint32_t BSZ = 1u << BS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
     static_assert(BS + SRC_BITS <= 32, "wide stage word: local target | source entry");
+    constexpr int BIN_EPT = NB > MAX_BINS ? FORA_BIN_EPT_WIDE : fora::BIN_EPT; // (shadows the namespace constant inside this kernel)
     constexpr uint32_t CHUNK = NT * BIN_EPT;
     __shared__ int64_t s_ebeg[NT];
     __shared__ uint64_t s_inc[NT];
@@ -2161,7 +2171,7 @@ __device__ __forceinline__ void stage_emit(const Dev &d, int q, WaveStage &st, b
 template <int NB>
 __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     constexpr int NT = BinThreads<NB>::value; // workgroup size = walk items per tile
-    constexpr int EPT = BIN_EPT;
+    constexpr int EPT = NB > MAX_BINS ? FORA_IDX_EPT_WIDE : BIN_EPT;
     constexpr uint32_t CHUNK = NT * EPT;
     constexpr bool BINNED = NB > 1;
     constexpr bool WIDE = NB > MAX_BINS;

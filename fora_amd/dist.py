@@ -73,3 +73,14 @@ def sum_over_ranks(values, world, device=None):
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
+
+
+def min_over_ranks(value, world, device=None):
+    import torch.distributed as _d
+    if world == 1 and not (_d.is_available() and _d.is_initialized()):
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())

@@ -83,11 +83,14 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["queries_total_per_step"] == 14
     assert weak["gather_in_global_order"] is True
     assert weak["ms_per_step"] >= 20.0  # the slower rank (rank 1 sleeps 20 ms per step) sets the time: max over ranks
+    # the line itself shows what torch.distributed saw and the spread over the ranks (rank 0 sleeps 10 ms, rank 1 20 ms)
+    assert weak["ranks"]["world_size_seen"] == 2 and weak["ranks"]["backend"] == "gloo" and weak["ranks"]["rccl"] is False
+    assert weak["ranks"]["per_rank_queries_per_s"]["min"] < weak["ranks"]["per_rank_queries_per_s"]["max"]
     strong = _bench("--gpus", "2", "--queries", "7", "--topk", "4", "--scaling", "strong")
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["queries_total_per_step"] == 7
     assert strong["gather_in_global_order"] is True
     one = _bench("--gpus", "1", "--queries", "5", "--topk", "3")
-    assert one["n_gpus"] == 1 and one["queries_total_per_step"] == 5
+    assert one["n_gpus"] == 1 and one["queries_total_per_step"] == 5 and one["ranks"]["world_size_seen"] == 1
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():

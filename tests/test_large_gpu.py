@@ -88,6 +88,39 @@ def test_medium_wide_layout_bit_exact(engine, oracle, medium):
     engine.clear_index()
 
 
+def test_webstanford_size_rmat_dangling(engine, oracle):
+    """The plain R-MAT variant of the headline graph: about 43 % of the nodes have no out-edge, so
+    dangling targets send their mass back to the source (algo.h:993-999, the hot `residue[s] +=` path) in nearly
+    every level, and dangling sources return at once (algo.h:961-965)."""
+    from fora_amd import synth
+    n, m, rp, col = synth.preset("webstanford", "rmat")
+    g = oracle.Graph(n, m, rp, col)
+    deg = g.deg
+    assert 0.3 < (deg == 0).mean() < 0.6
+    engine.clear_index()
+    engine.set_graph(n, m, rp, col)
+    engine.set_params(epsilon=0.5, seed=SEED)
+    rmax, omega = engine.get_params()
+    srcs = synth.query_set(n, 48, 17)
+    assert (deg[srcs] == 0).any() and (deg[srcs] > 0).any()
+    ppr, res, st = engine.query_fix(srcs[:12])
+    for i in range(12):
+        s = int(srcs[i])
+        assert int(ppr[i].sum()) == 1 << 62 and st[i]["ppr_sum_fix"] == 1 << 62
+        if deg[s] == 0:
+            assert st[i]["dangling_source"] == 1 and ppr[i][s] == 1 << 62 and st[i]["n_walks"] == 0   # ppr = e_s
+        else:
+            assert _exit_condition_holds(res[i], deg, rmax)
+            assert (res[i][deg == 0] == 0).all()                            # a dangling node never keeps residue
+    for i in [int(j) for j in np.flatnonzero(deg[srcs[:12]] > 0)[:2]]:     # two sources bit for bit against the twin
+        want, wres, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+        assert (res[i] == wres).all() and (ppr[i] == want).all()
+        assert st[i]["pops"] == wst["pops"] and st[i]["relax"] == wst["relax"] and st[i]["levels"] == wst["levels"]
+        assert st[i]["n_walks"] == wst["n_walks"]
+    _, st = engine.query(srcs, want_ppr=False)
+    assert all(s["ppr_sum_fix"] == 1 << 62 for s in st)
+
+
 def test_livejournal_with_idx(engine, oracle):
     """BASELINE config 3."""
     from fora_amd import synth
@@ -126,6 +159,17 @@ def test_livejournal_with_idx(engine, oracle):
     assert all(s["n_idx_hit"] == s["n_walks"] for s in st)
     assert st[0]["n_walks"] == wst["n_walks"]                             # batch position does not matter
     engine.clear_index()
+    # ---- top-k at this size: k = 500 --opt --with_idx (query.h:972-1045), two sources bit for bit against the twin
+    del idx, ppr, res, want, wres
+    engine.set_params(epsilon=0.5, opt=True, seed=SEED)
+    engine.build_index()
+    idx = engine.get_index()
+    ids, sc, rounds = engine.topk(srcs[:4], 500, epsilon=0.5, with_idx=True)
+    assert (np.diff(sc, axis=1) <= 0).all() and (sc[:, 0] > 0).all()
+    for i in range(2):
+        wid, wsc, wr, _ = oracle.twin_topk_query(g, int(srcs[i]), 500, 0.5, seed=SEED, index=idx)
+        assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+    engine.clear_index()
 
 
 def test_twitter2010_with_idx_and_topk(engine, oracle):
@@ -143,22 +187,25 @@ def test_twitter2010_with_idx_and_topk(engine, oracle):
     rmax, omega = engine.get_params()
     assert (rmax, omega) == oracle.fora_setting(n, m, 0.5)
     srcs = synth.query_set(n, 24, 13)
-    # ---- push of one source, bit for bit against the twin (about a minute and a half of CPU)
-    rsv, res, st = engine.push(srcs[:1])
     g = oracle.Graph(n, m, rp, col)
-    t = oracle.twin_push(g, int(srcs[0]), rmax)
-    assert (res[0] == t["residue"]).all() and (rsv[0] == t["reserve"]).all()
-    assert st[0]["pops"] == t["pops"] and st[0]["relax"] == t["relax"] and st[0]["levels"] == t["levels"]
-    assert _exit_condition_holds(res[0], deg, rmax)
-    del rsv, res, t
-    # ---- config 4: indexed queries
+    # ---- config 4: indexed queries.  One source bit for bit against the twin -- push (residue, pops, relaxations, levels)
+    # AND the indexed refinement (query.h:276-308) over the engine's own index: about a minute and a half of one core
     total, _, _ = engine.index_sizes()
     assert 2.8e9 < total < 3.4e9                                          # ~3.07e9 entries (11.4 GiB)
     engine.build_index()
+    idx = engine.get_index()
+    ppr, res, st = engine.query_fix(srcs[:1], with_idx=True)
+    want, wres, wst = oracle.twin_query(g, int(srcs[0]), rmax, omega, seed=SEED, index=idx)
+    assert (res[0] == wres).all() and (ppr[0] == want).all()
+    assert st[0]["pops"] == wst["pops"] and st[0]["relax"] == wst["relax"] and st[0]["levels"] == wst["levels"]
+    assert st[0]["n_walks"] == wst["n_walks"] == st[0]["n_idx_hit"] and int(ppr[0].sum()) == 1 << 62
+    assert _exit_condition_holds(res[0], deg, rmax)
+    del ppr, res, want, wres, idx
     _, st = engine.query(srcs, with_idx=True, want_ppr=False)
     assert all(s["ppr_sum_fix"] == 1 << 62 for s in st)                   # mass conserved exactly
     assert all(s["n_idx_hit"] == s["n_walks"] > 0 for s in st)            # 100 % index hit
     assert all(s["levels"] > 0 and s["pops"] > 0 for s in st if not s["dangling_source"])
+    assert st[0]["n_walks"] == wst["n_walks"]                             # batch position does not matter
     # ---- config 5: topk k = 500 --opt --with_idx (the --opt index: one-hop walks, build.h:328-329)
     engine.clear_index()
     engine.set_params(epsilon=0.5, opt=True, seed=SEED)
@@ -173,4 +220,10 @@ def test_twitter2010_with_idx_and_topk(engine, oracle):
         assert (ids[i, :k_pos] >= 0).all() and (ids[i, :k_pos] < n).all()
     ids2, sc2, rounds2 = engine.topk(srcs[:8], 500, epsilon=0.5, with_idx=True)
     assert (ids2 == ids).all() and (sc2 == sc).all() and (rounds2 == rounds).all()   # reproducible
+    # two sources bit for bit against the twin's top-k driver (ids, scores, rounds) with the engine's --opt index
+    idx = engine.get_index()
+    for i in range(2):
+        wid, wsc, wr, _ = oracle.twin_topk_query(g, int(srcs[i]), 500, 0.5, seed=SEED, index=idx)
+        assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+    del idx
     engine.clear_index()

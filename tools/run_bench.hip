@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 enum { READ = 0, WRITE = 1, RMW = 2 };
 __device__ __forceinline__ uint64_t mix(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -65,7 +66,68 @@ template <int MODE> double run(uint64_t *d_buf, uint64_t words, uint32_t run_byt
     hipEventDestroy(a); hipEventDestroy(b);
     return bytes / ms / 1e6; // GB/s
 }
+// ---- calibration of rocprofv3's FETCH_SIZE / WRITE_SIZE on known byte counts (`run_bench calib`): the same run pattern with 4-
+// and 8-byte words per lane, ONE dispatch per (word size, mode, run length), each touching `bytes` useful bytes exactly
+// once at pseudo-random run starts.  tools/pmc_calibrate.py divides the counters of a --pmc pass by these byte counts.
+template <int MODE, typename W>
+__global__ void __launch_bounds__(256) k_calib(W *buf, uint64_t words, uint32_t run_words, int steps, W *out) {
+    const uint32_t lpr = run_words < 64 ? run_words : 64;
+    const int lane = (threadIdx.x & 63) % lpr;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + (threadIdx.x & 63) / lpr;
+    const uint64_t slots = (words - run_words) / run_words; // run starts aligned to the run length
+    W acc = 0;
+    for (int s = 0; s < steps; s += 4) {
+        uint64_t base[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) base[u] = (mix(wave * 1000003ull + (uint64_t)(s + u)) % slots) * run_words;
+        for (uint32_t o = 0; o < run_words; o += 64) {
+            W v[4] = {0, 0, 0, 0};
+            if (o + lane < run_words) {
+                if (MODE != WRITE) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = buf[base[u] + o + lane];
+                }
+                if (MODE != READ) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) buf[base[u] + o + lane] = v[u] + (W)wave;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc += v[u];
+        }
+    }
+    if (acc == (W)0x1234567) out[0] = acc;
+}
+template <int MODE, typename W> void calib(void *d_buf, uint64_t buf_bytes, uint32_t run_bytes, void *d_out, int &disp) {
+    const uint32_t rw = run_bytes / sizeof(W);
+    const int blocks = 256 * 8 * 2;
+    const double runs_per_wave = rw < 64 ? 64.0 / rw : 1.0;
+    int steps = (int)(2.0e9 / ((double)blocks * 4 * runs_per_wave * run_bytes)); // about 2 GB per dispatch
+    steps = (steps + 3) / 4 * 4;
+    if (steps < 4) steps = 4;
+    hipLaunchKernelGGL((k_calib<MODE, W>), dim3(blocks), dim3(256), 0, 0, (W *)d_buf, buf_bytes / sizeof(W), rw, steps, (W *)d_out);
+    hipDeviceSynchronize();
+    const double bytes = (double)blocks * 4 * runs_per_wave * steps * run_bytes;
+    printf("CALIB %d %s word=%zu run=%u bytes=%.0f\n", disp++, MODE == READ ? "read" : MODE == WRITE ? "write" : "rmw", sizeof(W), run_bytes, bytes);
+}
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "calib")) {
+        const uint64_t bytes = 16ull << 30;
+        void *d_buf, *d_out;
+        if (hipMalloc(&d_buf, bytes) != hipSuccess || hipMalloc(&d_out, 8) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+        hipMemset(d_buf, 0, bytes);
+        hipDeviceSynchronize();
+        int disp = 0;
+        const uint32_t runs[] = {32, 64, 128, 256, 512, 4096, 65536};
+        for (uint32_t r : runs) {
+            calib<READ, uint32_t>(d_buf, bytes, r, d_out, disp);
+            calib<READ, uint64_t>(d_buf, bytes, r, d_out, disp);
+            calib<WRITE, uint32_t>(d_buf, bytes, r, d_out, disp);
+            calib<WRITE, uint64_t>(d_buf, bytes, r, d_out, disp);
+            calib<RMW, uint64_t>(d_buf, bytes, r, d_out, disp);
+        }
+        return 0;
+    }
     const double gb = argc > 1 ? atof(argv[1]) : 16;
     const uint32_t align = argc > 2 ? (uint32_t)atoi(argv[2]) : 8;
     const uint64_t words = (uint64_t)(gb * 1073741824.0 / 8);
