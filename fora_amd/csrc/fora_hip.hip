@@ -48,6 +48,7 @@ struct Tunables {
     int64_t defer = 0;           // bounded deferral of the bucketed push (Dev::defer_k): a node that crosses with less than 2^defer x its threshold waits one level; 0 (default): plain levels.
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
+    int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -57,7 +58,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, false}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 static Tunables tunables_from_env() {
@@ -488,6 +489,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
     d.defer_k = c->binned ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
+    d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
     d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
     d.dflag[0] = c->d_dflag; d.dflag[1] = c->d_dflag ? c->d_dflag + (size_t)c->B * c->nbins : nullptr;
     d.dl[0] = c->d_dl; d.dl[1] = c->d_dl ? c->d_dl + (size_t)c->B * c->n : nullptr;

@@ -230,6 +230,7 @@ struct Dev {
     // exactly one writer (the wave that sweeps those nodes).  dflag: the bin has marks at all (early exit of k_accum).
     // Word 2 of a slot's fl_count line counts the marks for the host's termination test.  k_push_tail keeps lists (dl).
     int32_t defer_k;        // 0: plain levels
+    uint32_t defer_min;     // only the levels that pop at least this many nodes of the slot defer (the long tail of small levels gains nothing from it)
     uint64_t *dbm[2];       // [slot][dbm_words]
     uint32_t dbm_words;     // per slot: nbins << (bin shift - 6)
     uint32_t *dflag[2];     // [slot][nbins]
@@ -1077,6 +1078,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
         __syncthreads();
         uint32_t crossed = min(s_next, (uint32_t)d.n);
         if (dk) {
+            const int dkl = real >= d.defer_min ? dk : 0; // this level defers only if it popped enough nodes
             // bounded deferral (see Dev::dbm): every add of the level has landed; a node that only just crossed becomes a
             // hole in the next list and waits in dl[par ^ 1]; the nodes that waited since the previous level join the list
             uint32_t *wait = d.dl[par ^ 1] + slab;
@@ -1084,7 +1086,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int m
             for (uint32_t i = tid; i < crossed; i += TAIL_THREADS) {
                 const uint32_t w = out[i];
                 const uint64_t r = __atomic_load_n(&d.residue[slab + w], __ATOMIC_RELAXED);
-                if ((r >> dk) < node_thr(d.t1, d.deg[w])) {
+                if (dkl && (r >> dkl) < node_thr(d.t1, d.deg[w])) {
                     out[i] = w | HOLE;
                     wait[atomicAdd(&s_nwait, 1u)] = w;
                 }
@@ -1181,7 +1183,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
     const bool din = !TO_PPR && s_din != 0;
     if (cnt == 0 && dm == 0 && ovn == 0 && !din) return;
-    const int dk = TO_PPR ? 0 : d.defer_k;
+    const int dk = (TO_PPR || !d.defer_k) ? 0 : (d.fl_count[par][q * CSTRIDE] >= d.defer_min ? d.defer_k : 0); // (the level's own frontier size: nothing writes it during the level)
     const uint32_t wpb = BSZ / 64; // bitmap words per bin
     uint64_t *dbm_in = TO_PPR ? nullptr : d.dbm[par] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
     uint64_t *dbm_out = TO_PPR ? nullptr : d.dbm[par ^ 1] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;

@@ -135,6 +135,7 @@ typedef struct {
 /* threshold rounds of orc_twin_push / orc_twin_query (the engine's option "rounds"; default 1) */
 void orc_twin_set_defer(int k); /* bounded deferral of the push (the engine's option "defer"; default 0: plain levels) */
 int orc_twin_get_defer(void);
+void orc_twin_set_defer_min(int64_t m); /* with defer: only levels that pop at least m nodes defer (option "defer_min"; default 0) */
 void orc_twin_set_rounds(int rounds);
 int orc_twin_get_rounds(void);
 void orc_twin_set_round_div(int div); /* 0 (default): a round ends when its frontier is empty */

@@ -64,6 +64,8 @@ void orc_fix_to_double(const uint64_t *in, int64_t n, double *out) {
 static int g_twin_defer = 0;
 void orc_twin_set_defer(int k) { g_twin_defer = k < 0 ? 0 : k > 8 ? 8 : k; }
 int orc_twin_get_defer(void) { return g_twin_defer; }
+static int64_t g_twin_defer_min = 0; /* only levels that pop at least this many nodes defer (option "defer_min") */
+void orc_twin_set_defer_min(int64_t m) { g_twin_defer_min = m < 0 ? 0 : m; }
 static int g_twin_rounds = 1;
 static int g_twin_round_div = 0;
 
@@ -149,7 +151,7 @@ static int64_t twin_levels_div(const int64_t *row_ptr, const int32_t *col, int32
             for (int64_t i = 0; i < ncross; i++) {
                 const int32_t w = cross[i];
                 const uint64_t thr = node_thr(t1, row_ptr[w + 1] - row_ptr[w]);
-                if ((residue[w] >> dk) < thr) wait[nwait++] = w;
+                if (fn >= g_twin_defer_min && (residue[w] >> dk) < thr) wait[nwait++] = w;
                 else next[nn++] = w;
             }
             int32_t *t = due; due = wait; wait = t;

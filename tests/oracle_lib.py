@@ -278,6 +278,10 @@ def twin_set_defer(k):
     lib().orc_twin_set_defer(C.c_int(int(k)))
 
 
+def twin_set_defer_min(m):
+    lib().orc_twin_set_defer_min(C.c_int64(int(m)))
+
+
 def twin_get_defer():
     return int(lib().orc_twin_get_defer())
 

@@ -418,13 +418,14 @@ def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds, div)
 
 
 @pytest.mark.parametrize("layout", ["narrow", "wide", "wide_multipass", "tail"])
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
-def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, layout):
+@pytest.mark.parametrize("k,dmin", [(0, 0), (1, 0), (2, 0), (3, 0), (1, 300), (2, 3000)])
+def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, dmin, layout):
     """Bounded deferral of the push (option "defer", Dev::defer_k): a node that crosses with less than 2^k x its
     threshold waits one level.  Every k equals the twin running the same schedule bit for bit -- in the bitmap form of
     the bucketed levels, the list form of k_push_tail and across the hand-over between them -- ends with the exit
     condition of algo.h:1012, conserves mass exactly, and k = 1 relaxes fewer edges and leaves less residue than plain
-    levels (k = 0, the default: the extra levels cost more on the GPU than the edges save)."""
+    levels (k = 0, the default: the extra levels cost more on the GPU than the edges save).  dmin: only
+    levels that pop at least that many nodes defer (option "defer_min")."""
     g = small_dangling
     if layout in ("wide", "wide_multipass"):
         engine.set_option("force_wide", 1)
@@ -441,7 +442,9 @@ def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, layout):
         engine.set_option("defer", 0)
         _, _, st0 = engine.push(srcs)
         engine.set_option("defer", k)
+        engine.set_option("defer_min", dmin)
         oracle.twin_set_defer(k)
+        oracle.twin_set_defer_min(dmin)
         rsv, res, st = engine.push(srcs)
         t1 = int(np.ceil(np.ldexp(rmax, 62)))
         for i, s in enumerate(srcs):
@@ -452,7 +455,7 @@ def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, layout):
             thr = (t1 * g.deg).astype(np.uint64)
             thr[g.deg == 0] = 1
             assert (res[i] < thr).all()
-        if k == 1:
+        if k == 1 and dmin == 0:
             assert sum(int(x["relax"]) for x in st) < sum(int(x["relax"]) for x in st0)
             assert sum(int(x["rsum_fix"]) for x in st) < sum(int(x["rsum_fix"]) for x in st0)
         ppr, _, stq = engine.query_fix(srcs[:3], want_residue=False)
@@ -462,6 +465,7 @@ def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, layout):
     finally:
         engine.reset_options()
         oracle.twin_set_defer(0)
+        oracle.twin_set_defer_min(0)
 
 
 def test_two_lane_pipeline_same_bits(engine, oracle, small, monkeypatch):

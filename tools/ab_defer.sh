@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: parity tests, then A/B of the bounded deferral (option defer) on the headline workload.
+# GPU box: deferral tests, then A/B of the bounded deferral (options defer / defer_min) on the headline workload.
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out
-timeout 1500 python3 -m pytest tests/test_hip_parity_gpu.py tests/test_edge_cases_gpu.py tests/test_golden.py -x -q -m gpu > gpurun_out/ab_tests.log 2>&1; echo "tests rc=$?"; tail -15 gpurun_out/ab_tests.log
+timeout 1500 python3 -m pytest tests/test_hip_parity_gpu.py -x -q -m gpu -k "deferral or push_paths or query_bit" > gpurun_out/ab_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/ab_tests.log
 run() { echo "== $*"; env "$@" python3 tools/pushbench.py --mode query --reps 3 $LIBS | python3 -c "
 import sys, json
 for l in sys.stdin:
@@ -12,7 +12,8 @@ for l in sys.stdin:
 "; }
 LIBS=""
 run FORA_HIP_DEFER=0
-run FORA_HIP_DEFER=1
-run FORA_HIP_DEFER=2
-run FORA_HIP_DEFER=1 FORA_HIP_TAIL=16384
-run FORA_HIP_DEFER=1 FORA_HIP_TAIL=65536
+run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=8192
+run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=16384
+run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=32768
+run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=50000
+run FORA_HIP_DEFER=2 FORA_HIP_DEFER_MIN=32768
