@@ -34,6 +34,8 @@ struct Tunables {
     int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
     int64_t walk_dg = 2;         // online walks over the degree-grouped copy (k_walk_dg): 0 never, 1 with one gather per walk for the endpoint's id, 2 results in bucket order; read by set_graph and at launch
+    int64_t hubs = 1024;         // narrow layout: increments for the `hubs` nodes of largest in-degree are summed per workgroup in LDS (Dev::col_hub); 0: off; read by set_graph.  ws, push of 1000 queries: 0 -> 79.5 ms, 1024 -> 75.6, 2048 -> 83.2, 4096 -> 90.5 (the LDS table costs the bin kernel its occupancy; the accumulate is bound by its sweep, not by its messages)
+    int64_t hub_min = 4096;      // ... in levels whose frontier holds at least this many nodes of the slot
     int64_t dg_hubs = 0;         // hub records of that copy (0: the fewest that leave <= 255 degree classes); read by set_graph
     int64_t bkcap = 0;           // bucket capacity in messages (0: default per layout)
     int64_t ovcap = 0;           // overflow list capacity (0: scales with the graph)
@@ -55,7 +57,7 @@ struct Tunables {
 };
 static const struct { const char *name; int64_t Tunables::*field; bool layout; } OPTIONS[] = {
     {"direct", &Tunables::direct, true}, {"force_wide", &Tunables::force_wide, true}, {"pass_bins", &Tunables::pass_bins, true},
-    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"bkcap", &Tunables::bkcap, true},
+    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
     {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, false}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
@@ -92,6 +94,10 @@ struct fora_ctx {
     int split_pbins = 0;
     uint32_t colbits = 0;
     // degree-grouped walk copy (WalkDG): device arrays + the scalars of the struct; dg.colp == nullptr: none
+    int32_t *d_col_hub = nullptr;    // hub pre-aggregation (Dev::col_hub)
+    uint32_t *d_hub_node = nullptr, *d_hub_first = nullptr;
+    uint32_t hubs = 0;
+    uint64_t *d_hubsum = nullptr;    // workspace: [B][sub][hubs]
     uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr, *d_dg_invb = nullptr;
     uint8_t *d_dg_T = nullptr;
     WalkDG dg{};
@@ -203,6 +209,7 @@ template <typename T> void dfree(T *&p) {
 
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
+    dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -222,7 +229,7 @@ void free_workspace(fora_ctx *c) {
     c->topk_cap = 0;
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
-    dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl);
+    dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -320,7 +327,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch +
-                     n * 4 * 2 + n / 4 + 64; // + deferred lists and bitmaps
+                     n * 4 * 2 + n / 4 + 64 + (want_wide(c) ? 0 : (uint64_t)p.sub * c->hubs * 8); // + deferred lists and bitmaps, hub sums
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -422,6 +429,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_dbm, 2 * (size_t)B * c->dbm_words * 8));
         HIPCHK(c, hipMalloc(&c->d_dflag, 2 * (size_t)B * p.nbins * 4));
         HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4));
+        if (c->hubs && !want_wide(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
         HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
@@ -488,6 +496,10 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.stamps = c->d_stamps;
     d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
+    if (c->binned && !want_wide(c) && c->d_col_hub && c->d_hubsum) {
+        d.col_hub = c->d_col_hub; d.hub_node = c->d_hub_node; d.hub_first = c->d_hub_first; d.hubsum = c->d_hubsum; d.hubs = c->hubs;
+        d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
+    }
     d.defer_k = c->binned ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
     d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
     d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
@@ -588,7 +600,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 int h = ev_begin(c, 1);
                 if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), 0, c->stream, dp, L);
                 else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
-                else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), 0, c->stream, dp, L);
+                else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
                 if (d.wide) hipLaunchKernelGGL((k_accum<false, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L);
@@ -933,6 +945,7 @@ int sync_twin(fora_ctx *c) {
     w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
     w->d_rp32 = c->d_rp32; w->d_colp = c->d_colp; w->colbits = c->colbits;
     w->dg = c->dg; // arrays owned by c
+    w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
@@ -1134,6 +1147,44 @@ int fora_hip_device_info(fora_ctx *c, char *arch, int arch_len, int *cus, uint64
 }
 
 
+// Hub pre-aggregation of the narrow push (Dev::col_hub): the `hubs` nodes of largest in-degree (ties: lower id), numbered in
+// id order so that the hubs of a bin are a contiguous range, and a copy of col that names them by that number.
+static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *col) {
+    (void)row_ptr;
+    const int32_t n = c->n;
+    const int64_t nnz = c->nnz;
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(c->opt_.hubs, 0), 7168); // 56 KB of LDS at most
+    if (want == 0 || nnz == 0 || want_wide(c) || c->opt_.direct == 1) return FORA_OK;
+    std::vector<uint32_t> indeg((size_t)n, 0);
+    for (int64_t e = 0; e < nnz; e++) indeg[(size_t)col[e]]++;
+    std::vector<uint32_t> order((size_t)n);
+    for (int32_t v = 0; v < n; v++) order[(size_t)v] = (uint32_t)v;
+    const size_t H = (size_t)std::min<int64_t>(want, n);
+    std::partial_sort(order.begin(), order.begin() + (long)H, order.end(),
+                      [&](uint32_t a, uint32_t b) { return indeg[a] != indeg[b] ? indeg[a] > indeg[b] : a < b; });
+    std::vector<uint32_t> hub_node(order.begin(), order.begin() + (long)H);
+    std::sort(hub_node.begin(), hub_node.end());
+    std::vector<uint32_t> hub_of((size_t)n, 0xFFFFFFFFu);
+    for (size_t h = 0; h < H; h++) hub_of[hub_node[h]] = (uint32_t)h;
+    const int nbins = (int)bins_of(c);
+    std::vector<uint32_t> first((size_t)nbins + 1, 0);
+    for (size_t h = 0; h < H; h++) first[(hub_node[h] >> BIN_SHIFT) + 1]++;
+    for (int b = 0; b < nbins; b++) first[(size_t)b + 1] += first[(size_t)b];
+    std::vector<int32_t> ch((size_t)nnz);
+    for (int64_t e = 0; e < nnz; e++) {
+        const uint32_t h = hub_of[(size_t)col[e]];
+        ch[(size_t)e] = h == 0xFFFFFFFFu ? col[e] : (int32_t)(0x80000000u | h);
+    }
+    HIPCHK(c, hipMalloc(&c->d_col_hub, (size_t)nnz * 4));
+    HIPCHK(c, hipMalloc(&c->d_hub_node, H * 4));
+    HIPCHK(c, hipMalloc(&c->d_hub_first, first.size() * 4));
+    HIPCHK(c, hipMemcpy(c->d_col_hub, ch.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_hub_node, hub_node.data(), H * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_hub_first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    c->hubs = (uint32_t)H;
+    return FORA_OK;
+}
+
 // Degree-grouped walk copy (WalkDG, fora_kernels.h) of graphs that run the narrow layout: H hub records + at most 255
 // out-degree classes whose tables fit a workgroup's LDS share.  Graphs that do not qualify keep k_walk_online.
 static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col) {
@@ -1295,6 +1346,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
     if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
+    if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
     return FORA_OK;
 }
 

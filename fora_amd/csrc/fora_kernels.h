@@ -213,6 +213,19 @@ struct Dev {
     const int32_t *col_push;   // == col when there is one pass
     const uint32_t *row_split; // [n][npass + 1] or null
     int32_t npass, pass;
+    // Hub pre-aggregation (narrow layout).  The `hubs` nodes of largest in-degree receive a large share of all
+    // increments (ws-sized R-MAT: the top 4096 of 282 k nodes are the target of 45 % of the edges).  In a level whose
+    // frontier holds at least hub_min nodes the bin kernel reads `col_hub` -- col with hub targets replaced by
+    // 0x80000000 | hub index -- and adds an increment for a hub to a per-workgroup LDS accumulator instead of emitting a
+    // message; the sums leave the workgroup as one dense row hubsum[slot][workgroup][hub] (plain coalesced stores), and
+    // the accumulate of the hub's bin adds the `sub` partial sums to its LDS accumulators like any other message.  Hub
+    // indices follow the node ids, so the hubs of one bin are a contiguous range [hub_first[b], hub_first[b + 1]).
+    // Integer adds commute: same bits as the plain messages.
+    const int32_t *col_hub;    // [nnz] or null
+    const uint32_t *hub_node;  // [hubs] node id of hub h
+    const uint32_t *hub_first; // [nbins + 1]
+    uint64_t *hubsum;          // [slot][sub][hubs]
+    uint32_t hubs, hub_min;
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
@@ -697,6 +710,11 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     constexpr bool WIDE = NB > MAX_BINS;
     if (WIDE && blockIdx.x == 0 && threadIdx.x == 0) d.tile_ctr[d.launch_par ^ 1][q * CSTRIDE] = 0; // for the next launch
     if (!count) return;
+    // hub pre-aggregation (see Dev::col_hub): the same predicate in k_accum decides whether hubsum is read
+    extern __shared__ unsigned long long s_hub[]; // [d.hubs] when hubmode
+    const bool hubmode = !WIDE && d.col_hub && count >= d.hub_min;
+    if (hubmode) for (uint32_t i = threadIdx.x; i < d.hubs; i += BinThreads<NB>::value) s_hub[i] = 0;
+    const int32_t *colsrc = hubmode ? d.col_hub : d.col_push;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
     constexpr uint32_t BSZ = 1u << BS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
@@ -794,7 +812,15 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             for (int k = 0; k < BIN_EPT; k++) { // straight-line: all BIN_EPT gathers in flight together
                 const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
-                if (e < total) w[k] = (uint32_t)d.col_push[s_ebeg[si[k]] + (e - s_pref[si[k]])];
+                if (e < total) w[k] = (uint32_t)colsrc[s_ebeg[si[k]] + (e - s_pref[si[k]])];
+            }
+            if (!WIDE && hubmode) {
+#pragma unroll
+                for (int k = 0; k < BIN_EPT; k++)
+                    if (w[k] != 0xFFFFFFFFu && (w[k] & 0x80000000u)) { // a hub: summed here, one row of sums per workgroup and level
+                        atomicAdd(&s_hub[w[k] & 0x7FFFFFFFu], (unsigned long long)s_inc[si[k]]);
+                        w[k] = 0xFFFFFFFFu;
+                    }
             }
 #pragma unroll
             for (int k = 0; k < BIN_EPT; k++) {
@@ -882,6 +908,11 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         STAMP(5);
     }
     for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
+    if (hubmode) { // the workgroup's row of hub sums (every workgroup of the slot writes one, with or without tiles: k_accum reads them all)
+        __syncthreads();
+        uint64_t *row = d.hubsum + ((uint64_t)q * sub + blockIdx.x) * d.hubs;
+        for (uint32_t i = threadIdx.x; i < d.hubs; i += NT) row[i] = s_hub[i];
+    }
     STAMP_FLUSH(0);
     if (!first_pass) return; // only the first pass pops
     // the slot's counters share one 128-byte line and one address takes ~20 M atomics/s: add them up over the workgroup
@@ -1182,7 +1213,10 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
     const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
     const bool din = !TO_PPR && s_din != 0;
-    if (cnt == 0 && dm == 0 && ovn == 0 && !din) return;
+    // hub pre-aggregation (Dev::col_hub): the level's bin kernel summed the increments of this bin's hubs per workgroup
+    const bool hubmode = !TO_PPR && !WIDE && d.col_hub && d.fl_count[par][q * CSTRIDE] >= d.hub_min;
+    const uint32_t hub_lo = hubmode ? d.hub_first[b] : 0, hub_hi = hubmode ? d.hub_first[b + 1] : 0;
+    if (cnt == 0 && dm == 0 && ovn == 0 && !din && hub_hi == hub_lo) return;
     const int dk = (TO_PPR || !d.defer_k) ? 0 : (d.fl_count[par][q * CSTRIDE] >= d.defer_min ? d.defer_k : 0); // (the level's own frontier size: nothing writes it during the level)
     const uint32_t wpb = BSZ / 64; // bitmap words per bin
     uint64_t *dbm_in = TO_PPR ? nullptr : d.dbm[par] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
@@ -1200,7 +1234,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const bool gather = !TO_PPR && !WIDE;
     const bool packed = !gather;
     const int pshift = WIDE ? BS : WPACK_SHIFT;
-    if (ovn == 0 && !din && cnt + (dm ? 1 : 0) <= d.tiny_max) {
+    if (ovn == 0 && !din && hub_hi == hub_lo && cnt + (dm ? 1 : 0) <= d.tiny_max) {
         // small bucket: zeroing and sweeping 64 KiB of LDS would cost more than its atomics (the workgroup owns the
         // node range and the level's pops are done, so nothing else touches these words).  Wave w takes sub-buckets
         // w, w + NW, ...
@@ -1331,6 +1365,15 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         }
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BSZ - 1)], (unsigned long long)dm);
+    if (!TO_PPR && !WIDE && hub_hi > hub_lo) { // the `sub` partial sums of every hub of this bin: rows of consecutive words
+        const uint32_t nh = hub_hi - hub_lo;
+        const uint64_t *rows = d.hubsum + (uint64_t)q * sub * d.hubs + hub_lo;
+        for (uint32_t i = threadIdx.x; i < nh * sub; i += AT) {
+            const uint32_t x = i / nh, h = i - x * nh;
+            const uint64_t v = NT_LOAD(&rows[(uint64_t)x * d.hubs + h]);
+            if (v) atomicAdd((unsigned long long *)&acc[d.hub_node[hub_lo + h] & (BSZ - 1)], (unsigned long long)v);
+        }
+    }
     for (uint32_t i = threadIdx.x; i < ovn; i += AT) { // increments whose bucket was full
         const uint32_t w = d.ov_w[(uint64_t)q * d.ov_cap + i];
         if ((int)(w >> BS) == b)
