@@ -60,7 +60,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, false}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 static Tunables tunables_from_env() {
@@ -327,7 +327,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch +
-                     n * 4 * 2 + n / 4 + 64 + (want_wide(c) ? 0 : (uint64_t)p.sub * c->hubs * 8); // + deferred lists and bitmaps, hub sums
+                     (c->opt_.defer > 0 ? n * 4 * 2 : 0) + n / 4 + 64 + (want_wide(c) ? 0 : (uint64_t)p.sub * c->hubs * 8); // + deferred lists and bitmaps, hub sums
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -428,7 +428,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         c->dbm_words = (uint32_t)((uint64_t)p.nbins << (bin_shift(c) - 6));
         HIPCHK(c, hipMalloc(&c->d_dbm, 2 * (size_t)B * c->dbm_words * 8));
         HIPCHK(c, hipMalloc(&c->d_dflag, 2 * (size_t)B * p.nbins * 4));
-        HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4));
+        if (c->opt_.defer > 0) HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4)); // k_push_tail's deferred lists: only with the option (changing it re-plans the workspace)
         if (c->hubs && !want_wide(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
@@ -500,7 +500,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
         d.col_hub = c->d_col_hub; d.hub_node = c->d_hub_node; d.hub_first = c->d_hub_first; d.hubsum = c->d_hubsum; d.hubs = c->hubs;
         d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
     }
-    d.defer_k = c->binned ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
+    d.defer_k = c->binned && c->d_dl ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
     d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
     d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
     d.dflag[0] = c->d_dflag; d.dflag[1] = c->d_dflag ? c->d_dflag + (size_t)c->B * c->nbins : nullptr;

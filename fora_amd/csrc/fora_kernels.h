@@ -62,6 +62,13 @@ constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin / k_walk
 #ifndef FORA_IDX_EPT_WIDE
 #define FORA_IDX_EPT_WIDE 12
 #endif
+// wide layouts: every (chunk, bin) run of messages is padded with null words to a multiple of this many messages, so
+// that it starts and ends on a 32-byte sector boundary (4 x 8 bytes).  Writes move whole sectors: an unaligned run of
+// R bytes costs (R + 24) / 32 sectors (profiles/r03_pmc_calibration.txt), and aligned sector writes are several times
+// faster than unaligned ones.  k_accum skips null words.  1: no padding.
+#ifndef FORA_RUN_PAD_WIDE
+#define FORA_RUN_PAD_WIDE 1
+#endif
 constexpr int SEG_BITS = 32 - BIN_SHIFT; // narrow push message = (target & (BIN_SIZE-1)) << SEG_BITS | frontier position
 // bucket messages are read exactly once: non-temporal loads keep them from displacing the increment table and the
 // slabs in L2 (accumulate kernels -1 %)
@@ -721,6 +728,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     static_assert(BS + SRC_BITS <= 32, "wide stage word: local target | source entry");
     constexpr int BIN_EPT = NB > MAX_BINS ? FORA_BIN_EPT_WIDE : fora::BIN_EPT; // (shadows the namespace constant inside this kernel)
     constexpr uint32_t CHUNK = NT * BIN_EPT;
+    constexpr uint32_t PAD = NB > MAX_BINS ? FORA_RUN_PAD_WIDE : 1;
     __shared__ int64_t s_ebeg[NT];
     __shared__ uint64_t s_inc[NT];
     __shared__ uint32_t s_pref[NT + 1];
@@ -850,7 +858,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) {
-                            s_fill[b] += c[j];
+                            s_fill[b] += (c[j] + (PAD - 1)) & ~(uint32_t)(PAD - 1);
                             s_cnt[b] = 0;
                         }
                     }
@@ -877,7 +885,8 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                 uint32_t sidx = 0, local;
                 if (WIDE) { sidx = e >> BS; local = e & (BSZ - 1); }
                 else local = e >> SEG_BITS; // narrow: the word names the frontier position
-                const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk: its messages end at s_fill[b]
+                const uint32_t crun = s_lofs[b + 1] - s_lofs[b]; // messages of this (chunk, bin) run
+                const uint32_t pos = s_fill[b] - ((crun + (PAD - 1)) & ~(uint32_t)(PAD - 1)) + (m - s_lofs[b]); // s_fill already counts this chunk's (padded) run
                 const uint64_t at = bk0 + (uint64_t)b * bstride + pos;
                 bool parked = pos >= d.bk_cap; // sub-bucket full
                 if (!parked) {
@@ -898,6 +907,16 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                         d.ov_inc[(uint64_t)q * d.ov_cap + oi] = s_inc[sidx];
                         atomicAdd(&d.ov_bin[par][(uint64_t)q * d.nbins + bin_lo + b], 1u);
                     } else atomicOr(d.err, ERR_BUCKET_OVERFLOW);
+                }
+            }
+            if (PAD > 1) { // null words up to the sector boundary (merged with the run's last sector in L2)
+                for (uint32_t b = threadIdx.x; b < bin_cnt; b += NT) {
+                    const uint32_t crun = s_lofs[b + 1] - s_lofs[b];
+                    const uint32_t prun = (crun + (PAD - 1)) & ~(uint32_t)(PAD - 1);
+                    for (uint32_t i = crun; i < prun; i++) {
+                        const uint32_t pos = s_fill[b] - prun + i;
+                        if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * bstride + pos] = 0ull;
+                    }
                 }
             }
             STAMP(4);
@@ -2218,6 +2237,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     constexpr int NT = BinThreads<NB>::value; // workgroup size = walk items per tile
     constexpr int EPT = NB > MAX_BINS ? FORA_IDX_EPT_WIDE : BIN_EPT;
     constexpr uint32_t CHUNK = NT * EPT;
+    constexpr uint32_t PAD = NB > MAX_BINS ? FORA_RUN_PAD_WIDE : 1;
     constexpr bool BINNED = NB > 1;
     constexpr bool WIDE = NB > MAX_BINS;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
@@ -2324,7 +2344,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
                         s_lofs[b] = pre2;
                         pre2 += c[j];
                         if (c[j]) { // space in the workgroup's own sub-bucket: a counter in LDS, no global atomic
-                            s_fill[b] += c[j];
+                            s_fill[b] += (c[j] + (PAD - 1)) & ~(uint32_t)(PAD - 1);
                             s_cnt[b] = 0;
                         }
                     }
@@ -2346,11 +2366,22 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
                 const uint32_t e = s_msg[m], b = s_bin[m];
                 const uint32_t dd = e & ((1u << DB) - 1);
                 const uint64_t wgt = s_incr[(e >> DB) & (uint32_t)(NT - 1)] + (e >> (DB + IB));
-                const uint32_t pos = s_fill[b] - s_lofs[b + 1] + m; // s_fill already counts this chunk
+                const uint32_t crun = s_lofs[b + 1] - s_lofs[b];
+                const uint32_t pos = s_fill[b] - ((crun + (PAD - 1)) & ~(uint32_t)(PAD - 1)) + (m - s_lofs[b]); // s_fill already counts this chunk's (padded) run
                 const bool fits = wgt < (WIDE ? WIDE_MAXV : WPACK_MAXW);
                 if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * sub * d.bk_cap + pos] = fits ? (uint64_t)dd | (wgt << DB) : 0ull;
                 if (pos >= d.bk_cap || !fits) // sub-bucket full / weight too large for the packed word: direct atomic, same sum
                     atomicAdd((unsigned long long *)&d.ppr[slab + (WIDE ? ((bin_lo + b) << BS) | dd : dd)], (unsigned long long)wgt);
+            }
+            if (PAD > 1) { // null words up to the sector boundary (see k_pushq_bin)
+                for (uint32_t b = threadIdx.x; b < bin_cnt; b += NT) {
+                    const uint32_t crun = s_lofs[b + 1] - s_lofs[b];
+                    const uint32_t prun = (crun + (PAD - 1)) & ~(uint32_t)(PAD - 1);
+                    for (uint32_t i = crun; i < prun; i++) {
+                        const uint32_t pos = s_fill[b] - prun + i;
+                        if (pos < d.bk_cap) d.bk_inc[bk0 + (uint64_t)b * sub * d.bk_cap + pos] = 0ull;
+                    }
+                }
             }
         }
         __syncthreads();

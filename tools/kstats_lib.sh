@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 export FORA_HIP_LIB="$(realpath $LIB)"
 OUT="$R/gpurun_out/kstats_tmp_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --no-accuracy --no-variants "$@" > "$OUT/kt.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu --no-accuracy --no-variants --no-configs "$@" > "$OUT/kt.log" 2>&1
 cp $(find "$OUT/kt" -name '*kernel_stats.csv' | head -1) "$R/gpurun_out/kstats_$TAG.csv" 2>/dev/null
 rm -rf "$OUT"
 python3 - "$R/gpurun_out/kstats_$TAG.csv" <<'PY'

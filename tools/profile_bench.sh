@@ -5,7 +5,7 @@ TAG="$1"; shift
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$R/gpurun_out/prof_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu --no-accuracy --no-variants $*"
+ARGS="--steps 1 --warmup 0 --no-cpu --no-accuracy --no-variants --no-configs $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format csv -- python3 "$R/bench.py" $ARGS > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- python3 "$R/bench.py" $ARGS > "$OUT/write.log" 2>&1

@@ -98,7 +98,20 @@ __global__ void __launch_bounds__(256) k_calib(W *buf, uint64_t words, uint32_t 
     }
     if (acc == (W)0x1234567) out[0] = acc;
 }
-template <int MODE, typename W> void calib(void *d_buf, uint64_t buf_bytes, uint32_t run_bytes, void *d_out, int &disp) {
+template <int MODE, typename W> void calib(void *d_buf, uint64_t buf_bytes, uint32_t run_bytes, void *d_out, int &disp, uint32_t align_bytes = 0) {
+    if (align_bytes) { // runs that start at any multiple of align_bytes: the write-out of the bin kernels (a few 8-byte messages per run)
+        const uint32_t rw = run_bytes / 8, aw = align_bytes / 8;
+        const int blocks = 256 * 8 * 2;
+        const double runs_per_wave = rw < 64 ? 64 / rw : 1.0;
+        int steps = (int)(2.0e9 / ((double)blocks * 4 * runs_per_wave * run_bytes));
+        steps = (steps + 3) / 4 * 4;
+        if (steps < 4) steps = 4;
+        hipLaunchKernelGGL(k_runs<MODE>, dim3(blocks), dim3(256), 0, 0, (uint64_t *)d_buf, buf_bytes / 8, rw, aw, steps, (uint64_t *)d_out);
+        hipDeviceSynchronize();
+        const double bytes = (double)blocks * 4 * runs_per_wave * steps * run_bytes;
+        printf("CALIB %d %s word=8 run=%u bytes=%.0f align=%u\n", disp++, MODE == READ ? "read" : MODE == WRITE ? "write" : "rmw", run_bytes, bytes, align_bytes);
+        return;
+    }
     const uint32_t rw = run_bytes / sizeof(W);
     const int blocks = 256 * 8 * 2;
     const double runs_per_wave = rw < 64 ? 64.0 / rw : 1.0;
@@ -125,6 +138,10 @@ int main(int argc, char **argv) {
             calib<WRITE, uint32_t>(d_buf, bytes, r, d_out, disp);
             calib<WRITE, uint64_t>(d_buf, bytes, r, d_out, disp);
             calib<RMW, uint64_t>(d_buf, bytes, r, d_out, disp);
+        }
+        for (uint32_t r : {8u, 16u, 24u, 40u, 56u, 104u, 232u}) { // unaligned short runs
+            calib<WRITE, uint64_t>(d_buf, bytes, r, d_out, disp, 8);
+            calib<READ, uint64_t>(d_buf, bytes, r, d_out, disp, 8);
         }
         return 0;
     }
