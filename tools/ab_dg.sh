@@ -1,6 +1,12 @@
 #!/bin/bash
-# GPU box: parity tests, then A/B of k_walk_dg variants (options and builds) on the headline workload.
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out
-timeout 1500 python3 -m pytest tests/test_hip_parity_gpu.py tests/test_edge_cases_gpu.py -x -q -m gpu > gpurun_out/ab_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/ab_tests.log
-FORA_HIP_WALK_DG=1 timeout 1500 python3 -m pytest tests/test_hip_parity_gpu.py -x -q -m gpu -k "query or walk or topk or batching" > gpurun_out/ab_tests1.log 2>&1; echo "tests(dg=1) rc=$?"; tail -2 gpurun_out/ab_tests1.log
+run() { echo "== $*"; env "$@" python3 tools/pushbench.py --mode query --reps 3 $LIBS | python3 -c "
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: print(l.strip()); continue
+    print('%-16s walk %.1f walk_accum %.1f alloc %.1f push %.1f batch %.1f' % (d['lib'], d['walk_ms'], d['walk_accum_ms'], d['walk_alloc_ms'], d['push_ms'], d['batch_ms']))
+"; }
+LIBS="fora_amd/libfora_hip.so variants/lib_ntst.so variants/lib_ntit.so variants/lib_ntboth.so variants/lib_wpe7.so"
+run FORA_HIP_WALK_DG=2
