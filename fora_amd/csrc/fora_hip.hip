@@ -1153,7 +1153,7 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     (void)row_ptr;
     const int32_t n = c->n;
     const int64_t nnz = c->nnz;
-    const int64_t want = std::min<int64_t>(std::max<int64_t>(c->opt_.hubs, 0), 7168); // 56 KB of LDS at most
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(c->opt_.hubs, 0), 6144); // 48 KB of dynamic LDS at most
     if (want == 0 || nnz == 0 || want_wide(c) || c->opt_.direct == 1) return FORA_OK;
     std::vector<uint32_t> indeg((size_t)n, 0);
     for (int64_t e = 0; e < nnz; e++) indeg[(size_t)col[e]]++;

@@ -111,13 +111,18 @@ def test_query_bit_exact_vs_twin(engine, oracle, request, gname, opt):
 
 
 @pytest.mark.parametrize("opt", [False, True])
-@pytest.mark.parametrize("copy", ["compact", "csr"])
+@pytest.mark.parametrize("copy", ["dg_bucket_order", "dg_gather", "dg_many_hubs", "compact", "csr"])
 def test_walk_graph_copies_agree(engine, oracle, small_dangling, copy, opt):
-    """The online walk kernel steps through the bit-packed compact copy of the graph (the default below 2^31 edges) or
-    the plain CSR, chosen at set_graph.  Same edge choice in both: queries and the index build equal the twin bit for
-    bit."""
+    """The online walks step through one of several copies of the graph, chosen at set_graph: the degree-grouped copy
+    (k_walk_dg, the default in the narrow layout: one gather per step; results in bucket order with hub endpoints summed
+    in LDS, or with one gather per walk for the endpoint's id; with the fewest or with 1024 hub records), the bit-packed
+    compact copy or the plain CSR (k_walk_online).  Same edge choice in all of them: queries -- with and without indexed
+    walks in front of the online ones -- and the index build equal the twin bit for bit."""
     g = small_dangling
     engine.set_option("no_compact", 1 if copy == "csr" else 0)
+    engine.set_option("walk_dg", {"dg_bucket_order": 2, "dg_many_hubs": 2, "dg_gather": 1}.get(copy, 0))
+    if copy == "dg_many_hubs":
+        engine.set_option("dg_hubs", 1024)
     try:
         rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
         srcs = np.concatenate([pick_sources(g, 3, 25), pick_sources(g, 1, 26, want_dangling=True)])
@@ -126,12 +131,53 @@ def test_walk_graph_copies_agree(engine, oracle, small_dangling, copy, opt):
             want, _, wst = oracle.twin_query(g, int(s), rmax, omega, opt=opt, seed=SEED)
             assert (ppr[i] == want).all() and st[i]["n_walks"] == wst["n_walks"]
         engine.build_index()
-        rw, _, _ = engine.get_index()
+        rw, off, cnt = engine.get_index()
         want_rw, _, _ = oracle.build_index(g, SEED, rmax, omega, opt=opt)
         assert (rw == want_rw).all()
+        # indexed walks first, online walks for what the index does not cover (query.h:290-307, 320-323): an index cut to
+        # a third of its entries per node makes both kernels work on the same query
+        cnt3 = cnt // 3
+        engine.set_index(rw, off, cnt3)
+        ppr, _, st = engine.query_fix(srcs[:3], with_idx=True, want_residue=False)
+        for i in range(3):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, opt=opt, seed=SEED, index=(rw, off, cnt3))
+            assert (ppr[i] == want).all() and st[i]["n_walks"] == wst["n_walks"] and st[i]["n_idx_hit"] == wst["n_idx_hit"]
+            assert st[i]["dangling_source"] or 0 < st[i]["n_idx_hit"] < st[i]["n_walks"]
     finally:
         engine.reset_options()
         engine.clear_index()
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+
+
+@pytest.mark.parametrize("hubs,hub_min", [(0, 1), (64, 1), (1024, 1), (1024, 200), (6144, 1)])
+def test_hub_preaggregation_bit_exact(engine, oracle, small_dangling, hubs, hub_min):
+    """Hub pre-aggregation of the narrow push (options "hubs", read by set_graph, and "hub_min"): increments for the
+    nodes of largest in-degree are summed per workgroup in LDS and reach the accumulate as one dense row of sums per
+    workgroup.  Integer adds commute: push, query and top-k equal the twin bit for bit for any number of hubs and from
+    any level size on."""
+    g = small_dangling
+    engine.set_option("hubs", hubs)
+    engine.set_option("hub_min", hub_min)
+    engine.set_option("tail", 0)  # every level through the bucketed kernels
+    try:
+        rmax, omega = _load(engine, g, epsilon=0.5)
+        srcs = np.concatenate([pick_sources(g, 6, 91), pick_sources(g, 1, 92, want_dangling=True)])
+        rsv, res, st = engine.push(srcs)
+        for i, s in enumerate(srcs):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+        ppr, _, stq = engine.query_fix(srcs[:3], want_residue=False)
+        for i in range(3):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+            assert (ppr[i] == want).all() and stq[i]["n_walks"] == wst["n_walks"]
+        engine.set_params(epsilon=0.5, opt=True, seed=SEED)
+        ids, sc, rounds = engine.topk(srcs[:2], 50, epsilon=0.5)
+        for i in range(2):
+            wid, wsc, wr, _ = oracle.twin_topk_query(g, int(srcs[i]), 50, 0.5, seed=SEED)
+            assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+    finally:
+        engine.reset_options()
         engine.set_graph(g.n, g.m, g.row_ptr, g.col)
 
 
