@@ -3,13 +3,13 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out
 T0=$(date +%s)
-timeout 1500 python3 -m pytest tests -x -q -m gpu > gpurun_out/s3_tests.log 2>&1; echo "tests rc=$? in $(( $(date +%s) - T0 )) s"; tail -3 gpurun_out/s3_tests.log
+timeout 1500 python3 -m pytest tests -x -q -m gpu > gpurun_out/re_tests.log 2>&1; echo "tests rc=$? in $(( $(date +%s) - T0 )) s"; tail -3 gpurun_out/re_tests.log
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 T0=$(date +%s)
-timeout 900 python3 bench.py > gpurun_out/s3_bench_default.json 2> gpurun_out/s3_bench_default.err; echo "bench rc=$? in $(( $(date +%s) - T0 )) s"
+timeout 900 python3 bench.py > gpurun_out/re_bench_default.json 2> gpurun_out/re_bench_default.err; echo "bench rc=$? in $(( $(date +%s) - T0 )) s"
 python3 - <<'PY'
 import json
-d = json.loads(open("gpurun_out/s3_bench_default.json").read().strip().splitlines()[-1])
+d = json.loads(open("gpurun_out/re_bench_default.json").read().strip().splitlines()[-1])
 print("headline %.0f q/s, ms/step %.1f, roofline %.3f traffic %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"]))
 print({k: round(v / d["steps"], 1) for k, v in d["phases"].items() if k.endswith("_ms")})
 print("dangling", {k: v for k, v in d["variants"]["dangling_rmat"].items() if k.startswith("value")})
