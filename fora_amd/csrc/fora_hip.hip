@@ -568,12 +568,36 @@ int check_dev_err(fora_ctx *c) {
 // Level loop of the push for the slots already initialised (level-0 frontier in place).
 // Launches run ahead of the host by SPEC levels: an empty level costs a few near-empty
 // launches, a host round trip per level would cost more.
-int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, int level_cap = 0) {
+int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, int level_cap = 0, bool round_start = false) {
+    const int nq = d.nq;
+    if (round_start && c->binned && level_cap <= 0 && d.rounds <= 1 && c->opt_.tail != 0) {
+        // A round of the top-k / --balanced drivers starts from every node at or over the round's threshold
+        // (k_topk_frontier), often a handful: when no slot's frontier is larger than what k_push_tail takes over at anyway,
+        // the whole round runs inside that kernel -- one launch instead of two per level plus the look-ahead levels
+        // (Twitter-2010-sized top-k: 391 level launches of mostly empty workgroups per 125 queries).
+        const int64_t tail_auto = std::min<int64_t>(32768, std::max<int64_t>(2048, (int64_t)nq * 32));
+        const uint32_t tail_max = (uint32_t)(c->opt_.tail < 0 ? tail_auto : c->opt_.tail);
+        uint32_t *cnt = c->h_flc;
+        HIPCHK(c, hipMemcpyAsync(cnt, d.fl_count[0], (size_t)nq * 4 * CSTRIDE, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint32_t fmax = 0;
+        for (int i = 0; i < nq; i++) fmax = std::max(fmax, cnt[(size_t)i * CSTRIDE]);
+        if (fmax == 0) { if (levels_run) *levels_run = 0; return FORA_OK; }
+        if (fmax <= tail_max) {
+            int h = ev_begin(c, 9);
+            hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, d, 0, 0);
+            ev_end(c, h);
+            c->timing.levels++;
+            if (levels_run) *levels_run = 1;
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("push: ") + hipGetErrorString(e));
+            return FORA_OK;
+        }
+    }
     hipEvent_t done[SPEC + 1];
     for (auto &e : done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int rc = FORA_OK;
     int L = 0;
-    const int nq = d.nq;
     const unsigned xb = c->binned ? c->sub : 1u; // producer workgroups per slot = sub-buckets per bucket (Dev::bk_w); ws at 1000 slots: 4 -> 196 ms, 8 -> 178, 16 -> 163, 32 -> 174
     // frontier size (largest slot) from which k_push_tail takes over; 0: never.  ws, push of 1000 queries (round 2's
     // tail kernel: no agent-scope fences, 4 relaxations in flight per lane): 1024: 86.3 ms, 4096: 85.2, 16384: 82.5,
@@ -836,7 +860,7 @@ int push_balanced(fora_ctx *c, const int32_t *sources, int nq, bool with_idx) {
         h = ev_begin(c, 4);
         hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, dr, (const uint8_t *)c->d_active);
         ev_end(c, h);
-        int rc = run_push_levels(c, dr);
+        int rc = run_push_levels(c, dr, nullptr, 0, true);
         if (rc) return rc;
         HIPCHK(c, hipMemcpy(c->h_qs.data(), c->d_qs, (size_t)nq * sizeof(QState), hipMemcpyDeviceToHost));
         for (int i = 0; i < nq; i++) {
@@ -1675,7 +1699,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             int h = ev_begin(c, 4);
             hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, d, (const uint8_t *)c->d_active);
             ev_end(c, h);
-            rc = run_push_levels(c, d); // algo.h:1020-1093
+            rc = run_push_levels(c, d, nullptr, 0, true); // algo.h:1020-1093
             if (rc) return rc;
             // compute_ppr_with_fwdidx_topk, query.h:521-636, into ppr2
             h = ev_begin(c, 4);
@@ -1837,7 +1861,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
             int h = ev_begin(c, 4);
             hipLaunchKernelGGL(k_topk_frontier, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, d, (const uint8_t *)c->d_active);
             ev_end(c, h);
-            rc = run_push_levels(c, d); // algo.h:1020-1093
+            rc = run_push_levels(c, d, nullptr, 0, true); // algo.h:1020-1093
             if (rc) return rc;
             // compute_ppr_with_fwdidx_topk_with_bound, query.h:639-750, into ppr2
             h = ev_begin(c, 4);

@@ -1625,7 +1625,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
             rr[u] = vu < (uint64_t)d.n ? d.residue[slab + vu] : 0;
             any |= rr[u] != 0;
         }
-        if (!__syncthreads_or(any)) continue;
+        if (!__syncthreads_or(any)) continue; // (loading the next trip ahead of this test: no change -- the kernel's time is the per-node work of the residue nodes)
         uint64_t num[SLAB_UNROLL], incr[SLAB_UNROLL], rem[SLAB_UNROLL], iav[SLAB_UNROLL], ipos[SLAB_UNROLL];
         uint32_t nseg[SLAB_UNROLL], mine = 0;
 #pragma unroll
