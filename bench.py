@@ -446,6 +446,7 @@ def run_workload(args, ctx, light=False):
         avg_ms = step_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
         traffic = None
+        traffic_upper = None
         traffic_note = None
         tpath = args.traffic or os.path.join(ROOT, "profiles", f"pmc_traffic_{args.graph}{'_idx' if args.with_idx else ''}.json")
         if os.path.exists(tpath):
@@ -463,6 +464,10 @@ def run_workload(args, ctx, light=False):
                                if k.startswith(prefixes[0]) or k.startswith("fora::k_push_tail"))
                 traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
                               for k in keys) / max(1, n_launch)
+                # calibration (profiles/r03_pmc_calibration.txt): FETCH_SIZE counts 64 B per request and a request of a streamed
+                # (>= 128 B, aligned) read moves 128 B, so the true bytes lie between the raw sum and this bound
+                traffic_upper = sum(2 * pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
+                                    for k in keys) / max(1, n_launch)
                 traffic_note = pmc.get("_note")
         by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / max(1, tm["push_expand_launches"])}
         if bucketed:
@@ -473,7 +478,7 @@ def run_workload(args, ctx, light=False):
             by_kernel["k_push_pop"] = tm["push_pop_ms"] / tm["push_pop_launches"]
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_upper_bound": traffic_upper, "traffic_source": traffic_note,
             "kernel": ("fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
                        if bucketed else "fora::k_push_expand"),
             "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
@@ -520,7 +525,7 @@ def summarize(d):
         r = d["roofline"]
         e["roofline"] = {k: r[k] for k in ("frac", "achieved", "peak", "unit", "kernel", "launches", "avg_launch_ms", "avg_ms_by_kernel",
                                            "algorithmic_bytes", "algorithmic_counts", "fifo_relaxations_per_query",
-                                           "gpu_relaxations_per_query", "traffic")}
+                                           "gpu_relaxations_per_query", "traffic", "traffic_upper_bound")}
     ph = d.get("phases", {})
     e["phases_ms_per_step"] = {k: v / max(1, d["steps"]) for k, v in ph.items() if k.endswith("_ms")}
     if "avg_rounds" in d["config"]:
