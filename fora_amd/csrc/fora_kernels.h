@@ -4,7 +4,9 @@
 //   forward push    algo.h:954-1018   -> k_pushq_bin<NB> + k_accum<false>, one pair per level and bin pass
 //                                        (k_push_pop + k_push_expand: the one-atomic-per-edge form, test reference)
 //   walk allocation query.h:270-287   -> k_walk_alloc<MODE>
-//   random walks    algo.h:124-166, query.h:288-323 -> k_walk_idx<NB>, k_walk_online<MODE>, k_accum<true>
+//   random walks    algo.h:124-166, query.h:288-323 -> k_walk_idx<NB>, k_walk_dg (online walks over the degree-grouped copy of the
+//                                        graph, narrow layout: one gather per step), k_walk_online<MODE> (wide layouts,
+//                                        index build), k_accum<true>
 //   index build     build.h:325-354   -> k_index_alloc + k_walk_online<WALK_TO_INDEX>
 //   top-k           query.h:972-1045, algo.h:578-610 -> k_topk_frontier, k_count_above, k_topk_select
 // Many source queries ("slots") run concurrently; slot q owns dense slabs residue[q*n .. (q+1)*n) and
