@@ -2550,8 +2550,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
 constexpr int DG_THREADS = FORA_DG_THREADS;
 constexpr int DG_STAGE = FORA_DG_STAGE;
 constexpr int DG_TILE = 256; // walk items per tile
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 template <bool BITS32>
 __device__ __forceinline__ uint32_t dg_colp_at(const WalkDG &g, uint32_t e) {
+    if (BITS32) { // narrow layout: entries of at most 20 bits, so ONE byte-aligned dword holds an entry (bit offset & 7 plus its width <= 32)
+        const uint32_t at = g.bits * e;
+        const uint32_t w = *(const u32_unaligned *)((const char *)g.colp + (at >> 3));
+        return (w >> (at & 7)) & ((1u << g.bits) - 1u);
+    }
     uint32_t word, sh;
     if (BITS32) { const uint32_t at = g.bits * e; word = at >> 5; sh = at & 31; }
     else { const uint64_t at = (uint64_t)g.bits * e; word = (uint32_t)(at >> 5); sh = (uint32_t)at & 31; }
