@@ -98,3 +98,16 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-only", "--gpus", "4"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_fifo_counts_are_scaled_by_the_gpu_counters():
+    """bench.py credits the push with the FIFO oracle's pops / relaxations; its CPU sample covers the first sources only,
+    so it is scaled to the whole query set by the GPU schedule's own per-query counters."""
+    sys.path.insert(0, ROOT)
+    import bench
+    stats = [{"pops": 100, "relax": 1000}, {"pops": 300, "relax": 3000}, {"pops": 10, "relax": 50}, {"pops": 90, "relax": 950}]
+    tm = {"pops": 2 * 500, "relax": 2 * 5000}  # two timed steps over the four queries
+    p, e, how = bench.scale_fifo_counts(fifo_pops=320, fifo_relax=3000, k=2, stats=stats, tm=tm, q_timed=8)
+    assert abs(p - 0.8 * 125) < 1e-9 and abs(e - 0.75 * 1250) < 1e-9      # (FIFO / GPU on the first two) x (GPU mean over all)
+    assert how.startswith("sequential FIFO oracle") and "first 2 sources" in how
+    assert bench.scale_fifo_counts(0, 0, 0, stats, tm, 8)[0] is None
