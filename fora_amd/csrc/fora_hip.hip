@@ -35,6 +35,8 @@ struct Tunables {
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
     int64_t walk_dg = 2;         // online walks over the degree-grouped copy (k_walk_dg): 0 never, 1 with one gather per walk for the endpoint's id, 2 results in bucket order; read by set_graph and at launch
     int64_t hubs = 1024;         // narrow layout: increments for the `hubs` nodes of largest in-degree are summed per workgroup in LDS (Dev::col_hub); 0: off; read by set_graph.  ws, push of 1000 queries: 0 -> 79.5 ms, 1024 -> 75.6, 2048 -> 83.2, 4096 -> 90.5 (the LDS table costs the bin kernel its occupancy; the accumulate is bound by its sweep, not by its messages)
+    int64_t hubs_wide = -1;      // the same for graphs that run the wide layout in one pass per level; -1: 2048 up to 2^28 edges, else 0 (off); read by set_graph.
+                                 // LJ-sized push of 280 queries: 0 -> 560.8 ms, 1024 -> 558.7, 2048 -> 550.6, 4096 -> 681.6; Twitter-2010-sized: no gain (the top 2048 of 41.6 M nodes receive few of the edges)
     int64_t hub_min = 4096;      // ... in levels whose frontier holds at least this many nodes of the slot
     int64_t dg_hubs = 0;         // hub records of that copy (0: the fewest that leave <= 255 degree classes); read by set_graph
     int64_t bkcap = 0;           // bucket capacity in messages (0: default per layout)
@@ -57,7 +59,7 @@ struct Tunables {
 };
 static const struct { const char *name; int64_t Tunables::*field; bool layout; } OPTIONS[] = {
     {"direct", &Tunables::direct, true}, {"force_wide", &Tunables::force_wide, true}, {"pass_bins", &Tunables::pass_bins, true},
-    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
+    {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
     {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
@@ -97,6 +99,7 @@ struct fora_ctx {
     int32_t *d_col_hub = nullptr;    // hub pre-aggregation (Dev::col_hub)
     uint32_t *d_hub_node = nullptr, *d_hub_first = nullptr;
     uint32_t hubs = 0;
+    int hub_shift = 0;               // bin shift the hub ranges were built for
     uint64_t *d_hubsum = nullptr;    // workspace: [B][sub][hubs]
     uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr, *d_dg_invb = nullptr;
     uint8_t *d_dg_T = nullptr;
@@ -327,7 +330,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
         p.segq_cap = n; // frontier positions
         p.scratch = p.wits * sizeof(WalkItem);
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch +
-                     (c->opt_.defer > 0 ? n * 4 * 2 : 0) + n / 4 + 64 + (want_wide(c) ? 0 : (uint64_t)p.sub * c->hubs * 8); // + deferred lists and bitmaps, hub sums
+                     (c->opt_.defer > 0 ? n * 4 * 2 : 0) + n / 4 + 64 + (uint64_t)p.sub * c->hubs * 8; // + deferred lists and bitmaps, hub sums
     } else {
         p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
         p.per_slot = n * 8 * 4 + p.scratch;
@@ -429,7 +432,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_dbm, 2 * (size_t)B * c->dbm_words * 8));
         HIPCHK(c, hipMalloc(&c->d_dflag, 2 * (size_t)B * p.nbins * 4));
         if (c->opt_.defer > 0) HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4)); // k_push_tail's deferred lists: only with the option (changing it re-plans the workspace)
-        if (c->hubs && !want_wide(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
+        if (c->hubs && c->hub_shift == bin_shift(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
         HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
@@ -496,7 +499,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.stamps = c->d_stamps;
     d.round_div = 0;
     d.rounds = 1; // the query / push entry points raise it (k_round_sweep); top-k, --balanced and power iteration drive their own rounds
-    if (c->binned && !want_wide(c) && c->d_col_hub && c->d_hubsum) {
+    if (c->binned && c->d_col_hub && c->d_hubsum && c->hub_shift == bin_shift(c) && c->pbins >= c->nbins) { // one pass per level only: the passes of larger graphs read a row-sorted copy
         d.col_hub = c->d_col_hub; d.hub_node = c->d_hub_node; d.hub_first = c->d_hub_first; d.hubsum = c->d_hubsum; d.hubs = c->hubs;
         d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
     }
@@ -622,8 +625,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 dp.launch_par = (int32_t)(c->bin_launches++ & 1);
                 int h = ev_begin(c, 1);
-                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), 0, c->stream, dp, L);
-                else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), 0, c->stream, dp, L);
+                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
+                else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
                 else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
                 ev_end(c, h);
                 h = ev_begin(c, 6);
@@ -969,7 +972,7 @@ int sync_twin(fora_ctx *c) {
     w->d_row_ptr = c->d_row_ptr; w->d_col = c->d_col; w->d_rowinfo = c->d_rowinfo; w->d_deg = c->d_deg;
     w->d_rp32 = c->d_rp32; w->d_colp = c->d_colp; w->colbits = c->colbits;
     w->dg = c->dg; // arrays owned by c
-    w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs;
+    w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
@@ -1177,8 +1180,9 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     (void)row_ptr;
     const int32_t n = c->n;
     const int64_t nnz = c->nnz;
-    const int64_t want = std::min<int64_t>(std::max<int64_t>(c->opt_.hubs, 0), 6144); // 48 KB of dynamic LDS at most
-    if (want == 0 || nnz == 0 || want_wide(c) || c->opt_.direct == 1) return FORA_OK;
+    const int64_t wide_auto = nnz <= (1ll << 28) ? 2048 : 0;
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : c->opt_.hubs, 0), 6144); // 48 KB of dynamic LDS at most
+    if (want == 0 || nnz == 0 || c->opt_.direct == 1) return FORA_OK;
     std::vector<uint32_t> indeg((size_t)n, 0);
     for (int64_t e = 0; e < nnz; e++) indeg[(size_t)col[e]]++;
     std::vector<uint32_t> order((size_t)n);
@@ -1192,7 +1196,7 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     for (size_t h = 0; h < H; h++) hub_of[hub_node[h]] = (uint32_t)h;
     const int nbins = (int)bins_of(c);
     std::vector<uint32_t> first((size_t)nbins + 1, 0);
-    for (size_t h = 0; h < H; h++) first[(hub_node[h] >> BIN_SHIFT) + 1]++;
+    for (size_t h = 0; h < H; h++) first[(hub_node[h] >> bin_shift(c)) + 1]++;
     for (int b = 0; b < nbins; b++) first[(size_t)b + 1] += first[(size_t)b];
     std::vector<int32_t> ch((size_t)nnz);
     for (int64_t e = 0; e < nnz; e++) {
@@ -1206,6 +1210,7 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     HIPCHK(c, hipMemcpy(c->d_hub_node, hub_node.data(), H * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_hub_first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     c->hubs = (uint32_t)H;
+    c->hub_shift = bin_shift(c);
     return FORA_OK;
 }
 

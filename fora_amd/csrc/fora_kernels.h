@@ -222,7 +222,7 @@ struct Dev {
     const int32_t *col_push;   // == col when there is one pass
     const uint32_t *row_split; // [n][npass + 1] or null
     int32_t npass, pass;
-    // Hub pre-aggregation (narrow layout).  The `hubs` nodes of largest in-degree receive a large share of all
+    // Hub pre-aggregation (single-pass layouts).  The `hubs` nodes of largest in-degree receive a large share of all
     // increments (ws-sized R-MAT: the top 4096 of 282 k nodes are the target of 45 % of the edges).  In a level whose
     // frontier holds at least hub_min nodes the bin kernel reads `col_hub` -- col with hub targets replaced by
     // 0x80000000 | hub index -- and adds an increment for a hub to a per-workgroup LDS accumulator instead of emitting a
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     if (!count) return;
     // hub pre-aggregation (see Dev::col_hub): the same predicate in k_accum decides whether hubsum is read
     extern __shared__ unsigned long long s_hub[]; // [d.hubs] when hubmode
-    const bool hubmode = !WIDE && d.col_hub && count >= d.hub_min;
+    const bool hubmode = d.col_hub && count >= d.hub_min;
     if (hubmode) for (uint32_t i = threadIdx.x; i < d.hubs; i += BinThreads<NB>::value) s_hub[i] = 0;
     const int32_t *colsrc = hubmode ? d.col_hub : d.col_push;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                 w[k] = 0xFFFFFFFFu;
                 if (e < total) w[k] = (uint32_t)colsrc[s_ebeg[si[k]] + (e - s_pref[si[k]])];
             }
-            if (!WIDE && hubmode) {
+            if (hubmode) {
 #pragma unroll
                 for (int k = 0; k < BIN_EPT; k++)
                     if (w[k] != 0xFFFFFFFFu && (w[k] & 0x80000000u)) { // a hub: summed here, one row of sums per workgroup and level
@@ -1235,7 +1235,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
     const bool din = !TO_PPR && s_din != 0;
     // hub pre-aggregation (Dev::col_hub): the level's bin kernel summed the increments of this bin's hubs per workgroup
-    const bool hubmode = !TO_PPR && !WIDE && d.col_hub && d.fl_count[par][q * CSTRIDE] >= d.hub_min;
+    const bool hubmode = !TO_PPR && d.col_hub && d.fl_count[par][q * CSTRIDE] >= d.hub_min;
     const uint32_t hub_lo = hubmode ? d.hub_first[b] : 0, hub_hi = hubmode ? d.hub_first[b + 1] : 0;
     if (cnt == 0 && dm == 0 && ovn == 0 && !din && hub_hi == hub_lo) return;
     const int dk = (TO_PPR || !d.defer_k) ? 0 : (d.fl_count[par][q * CSTRIDE] >= d.defer_min ? d.defer_k : 0); // (the level's own frontier size: nothing writes it during the level)
@@ -1386,7 +1386,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         }
     }
     if (threadIdx.x == 0 && dm) atomicAdd((unsigned long long *)&acc[s & (BSZ - 1)], (unsigned long long)dm);
-    if (!TO_PPR && !WIDE && hub_hi > hub_lo) { // the `sub` partial sums of every hub of this bin: rows of consecutive words
+    if (!TO_PPR && hub_hi > hub_lo) { // the `sub` partial sums of every hub of this bin: rows of consecutive words
         const uint32_t nh = hub_hi - hub_lo;
         const uint64_t *rows = d.hubsum + (uint64_t)q * sub * d.hubs + hub_lo;
         for (uint32_t i = threadIdx.x; i < nh * sub; i += AT) {

@@ -149,14 +149,19 @@ def test_walk_graph_copies_agree(engine, oracle, small_dangling, copy, opt):
         engine.set_graph(g.n, g.m, g.row_ptr, g.col)
 
 
-@pytest.mark.parametrize("hubs,hub_min", [(0, 1), (64, 1), (1024, 1), (1024, 200), (6144, 1)])
-def test_hub_preaggregation_bit_exact(engine, oracle, small_dangling, hubs, hub_min):
+@pytest.mark.parametrize("hubs,hub_min,wide", [(0, 1, False), (64, 1, False), (1024, 1, False), (1024, 200, False), (6144, 1, False),
+                                                  (512, 1, True), (2048, 100, True)])
+def test_hub_preaggregation_bit_exact(engine, oracle, small_dangling, hubs, hub_min, wide):
     """Hub pre-aggregation of the narrow push (options "hubs", read by set_graph, and "hub_min"): increments for the
     nodes of largest in-degree are summed per workgroup in LDS and reach the accumulate as one dense row of sums per
     workgroup.  Integer adds commute: push, query and top-k equal the twin bit for bit for any number of hubs and from
     any level size on."""
     g = small_dangling
-    engine.set_option("hubs", hubs)
+    if wide:  # the wide layout (8-byte messages) in one pass per level; option "hubs_wide"
+        engine.set_option("force_wide", 1)
+        engine.set_option("hubs_wide", hubs)
+    else:
+        engine.set_option("hubs", hubs)
     engine.set_option("hub_min", hub_min)
     engine.set_option("tail", 0)  # every level through the bucketed kernels
     try:
