@@ -117,3 +117,49 @@ def test_c_binding_runs_end_to_end():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "c smoke ok" in r.stdout
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_small_graphs_vs_twin(engine, oracle, seed):
+    """Differential check on a dozen random graph shapes -- sparse / dense, with and without dangling nodes, power-law and
+    uniform degrees, duplicate edges, fewer nodes than hub records, sizes just around the 64-id blocks and 8192-node bins
+    of the internal copies: query (online walks over the degree-grouped copy, hub pre-aggregation from the first level on),
+    --opt, an indexed query and top-k equal the twin bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    n = int([37, 64, 65, 200, 257, 1000, 4095, 8192, 8193, 9000, 20000, 33000][seed])
+    avg = float(rng.choice([0.7, 2.0, 6.0, 20.0]))
+    m = max(1, int(n * avg))
+    if seed % 3 == 0:   # power-law sources and targets, duplicates kept (graph.h:158)
+        src = np.minimum((n * rng.random(m) ** 3).astype(np.int64), n - 1)
+        dst = np.minimum((n * rng.random(m) ** 2).astype(np.int64), n - 1)
+    elif seed % 3 == 1:  # uniform, many dangling nodes when avg < 1
+        src = rng.integers(0, n, m)
+        dst = rng.integers(0, n, m)
+    else:                # a few giant rows over a sparse background
+        hubs = rng.integers(0, n, 3)
+        src = np.concatenate([rng.integers(0, n, m // 2), rng.choice(hubs, m - m // 2)])
+        dst = rng.integers(0, n, m)
+    g = oracle.Graph.from_edges(n, m, src.astype(np.int32), dst.astype(np.int32))
+    engine.set_option("hub_min", 1)
+    engine.set_option("tail", 64)
+    try:
+        for opt in (False, True):
+            rmax, omega = _load(engine, g, epsilon=0.5, opt=opt)
+            srcs = rng.integers(0, n, 5).astype(np.int32)
+            _check_queries(engine, oracle, g, srcs, rmax, omega, opt=opt)
+        # opt=True parameters are loaded: index + top-k in the driver's flavour
+        engine.build_index()
+        idx = engine.get_index()
+        pi, _, st = engine.query_fix(srcs[:2], with_idx=True, want_residue=False)
+        for i in range(2):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, opt=True, seed=SEED, index=idx)
+            assert (pi[i] == want).all() and st[i]["n_idx_hit"] == wst["n_idx_hit"]
+        k = 8
+        if n - 1 > k >= 2:
+            ids, sc, rounds = engine.topk(srcs[:2], k, epsilon=0.5, with_idx=True)
+            for i in range(2):
+                wid, wsc, wr, _ = oracle.twin_topk_query(g, int(srcs[i]), k, 0.5, seed=SEED, index=idx)
+                assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+    finally:
+        engine.clear_index()
+        engine.reset_options()
