@@ -2549,7 +2549,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
 #endif
 constexpr int DG_THREADS = FORA_DG_THREADS;
 constexpr int DG_STAGE = FORA_DG_STAGE;
-constexpr int DG_TILE = 256; // walk items per tile
+#ifndef FORA_DG_TILE
+#define FORA_DG_TILE 256
+#endif
+constexpr int DG_TILE = FORA_DG_TILE; // walk items per tile (at most DG_THREADS)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 template <bool BITS32>
 __device__ __forceinline__ uint32_t dg_colp_at(const WalkDG &g, uint32_t e) {
