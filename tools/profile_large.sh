@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: kernel stats + PMC traffic of the LJ- and Twitter-2010-sized workloads (tools/profile_bench.sh) -> gpurun_out/prof_r03c_{lj,tw}/
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"
 bash tools/profile_bench.sh r03c_lj --graph livejournal --with-idx > gpurun_out/prof_r03c_lj.log 2>&1
