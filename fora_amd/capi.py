@@ -45,7 +45,8 @@ class Timing(C.Structure):
                 ("push_pop_launches", C.c_uint64), ("push_expand_launches", C.c_uint64), ("push_accum_launches", C.c_uint64),
                 ("walk_launches", C.c_uint64), ("batches", C.c_uint64), ("pops", C.c_uint64),
                 ("relax", C.c_uint64), ("walks", C.c_uint64), ("walk_steps", C.c_uint64),
-                ("levels", C.c_uint64), ("idx_hits", C.c_uint64), ("push_tail_ms", C.c_double), ("push_tail_launches", C.c_uint64)]
+                ("levels", C.c_uint64), ("idx_hits", C.c_uint64), ("push_tail_ms", C.c_double), ("push_tail_launches", C.c_uint64),
+                ("push_team_ms", C.c_double), ("push_team_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -4,6 +4,7 @@
 // workspace of `batch` query slots.  The host side only sequences kernel launches;
 // there is no CPU fallback: without a HIP device every entry point fails.
 #include "fora_kernels.h"
+#include "fora_team.h"
 #include "../../include/fora_hip.h"
 
 #include <algorithm>
@@ -20,7 +21,7 @@ namespace {
 
 struct EvPair {
     hipEvent_t a, b;
-    int kind; // 0 pop, 1 expand, 2 walk_alloc, 3 walk, 4 other, 5 batch, 6 accum, 7 walk accum, 8 round sweep, 9 tail
+    int kind; // 0 pop, 1 expand, 2 walk_alloc, 3 walk, 4 other, 5 batch, 6 accum, 7 walk accum, 8 round sweep, 9 tail, 10 team push
 };
 
 } // namespace
@@ -53,6 +54,11 @@ struct Tunables {
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
+    int64_t team = 1;            // 1: graphs of the narrow layout push with k_push_team (residue resident in LDS, fora_team.h); 0: the bucketed kernels (read by set_graph and at launch)
+    int64_t team_size = 0;       // members per team (a power of two up to 32); 0: the fewest whose LDS holds the graph; read by set_graph
+    int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: default
+    int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
+    int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -62,7 +68,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 static Tunables tunables_from_env() {
@@ -104,6 +110,15 @@ struct fora_ctx {
     uint32_t *d_dg_perm = nullptr, *d_dg_inv = nullptr, *d_dg_colp = nullptr, *d_dg_rec = nullptr, *d_dg_invb = nullptr;
     uint8_t *d_dg_T = nullptr;
     WalkDG dg{};
+    // team push (fora_team.h): target copy of col, bucket offsets; built by set_graph for graphs of the narrow layout
+    uint32_t *d_colt = nullptr, *d_team_off = nullptr;
+    uint32_t team_T = 0, team_R = 0;
+    uint64_t team_cap = 0;           // message slots per (team, parity)
+    // ... and its workspace
+    uint64_t *d_team_msg = nullptr;
+    uint32_t *d_team_cnt = nullptr, *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
+    uint32_t team_n = 0;             // teams of a launch
+    bool team_attr = false;          // dynamic LDS limit of k_push_team raised
 
     // params
     bool have_params = false;
@@ -213,6 +228,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
+    dfree(c->d_colt); dfree(c->d_team_off); c->team_T = 0; c->team_R = 0; c->team_cap = 0;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -233,6 +249,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
+    dfree(c->d_team_msg); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -375,8 +392,66 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
     return FORA_OK;
 }
 
+// Team push (fora_team.h): members per team for this graph (0: the graph does not take the team path), the copy of
+// col that names every target as (owner, local id) and the exact bucket capacities.  Built on first use and whenever
+// the `team` / `team_size` options ask for another shape.
+static uint32_t want_team_size(const fora_ctx *c) {
+    if (c->opt_.team != 1 || !want_binned(c) || want_wide(c) || c->nnz == 0) return 0;
+    const uint64_t nblk = ((uint64_t)c->n + 63) / 64, maxblk = TEAM_R_CAP / 64;
+    uint32_t T = 1;
+    while (T <= (uint32_t)TEAM_MAX && (nblk + T - 1) / T > maxblk) T *= 2;
+    if (c->opt_.team_size > 0) {
+        uint32_t f = 1;
+        while (f < (uint32_t)c->opt_.team_size && f < (uint32_t)TEAM_MAX) f *= 2;
+        T = std::max(T, f);
+    }
+    if (T > (uint32_t)TEAM_MAX || T > (uint32_t)std::max(1, c->prop.multiProcessorCount)) return 0;
+    return T;
+}
+int ensure_team(fora_ctx *c) {
+    if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
+    const uint32_t T = want_team_size(c);
+    if (T == c->team_T && (T == 0 || c->d_colt)) return FORA_OK;
+    dfree(c->d_colt); dfree(c->d_team_off);
+    c->team_T = 0; c->team_R = 0; c->team_cap = 0;
+    if (T == 0) return FORA_OK;
+    const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
+    const uint32_t nblk = (uint32_t)((n + 63) / 64);
+    const uint32_t R = ((nblk + T - 1) / T) * 64;
+    std::vector<int32_t> col(nnz);
+    HIPCHK(c, hipMemcpy(col.data(), c->d_col, nnz * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> colt(nnz);
+    std::vector<uint64_t> pair((size_t)T * T, 0);
+    for (size_t v = 0; v < n; v++) {
+        const uint32_t s = (uint32_t)((v >> 6) % T);
+        for (int64_t e = c->h_row_ptr[v]; e < c->h_row_ptr[v + 1]; e++) {
+            const uint32_t w = (uint32_t)col[(size_t)e], b = w >> 6;
+            const uint32_t dd = b % T, local = ((b / T) << 6) | (w & 63u);
+            colt[(size_t)e] = (dd << TEAM_LBITS) | local;
+            pair[(size_t)s * T + dd]++;
+        }
+    }
+    // bucket (s -> d): one message per edge, a second word for increments of 2^48 and more (at most 2^14 of them fit the
+    // unit mass), the dangling mass of the level (two words); whole 128-byte lines
+    std::vector<uint32_t> off((size_t)T * T + 1, 0);
+    uint64_t at = 0;
+    for (size_t i = 0; i < (size_t)T * T; i++) {
+        off[i] = (uint32_t)at;
+        at += (pair[i] + std::min<uint64_t>(pair[i], 16384) + 2 + 15) & ~15ull;
+        if (at >= (1ull << 32)) return FORA_OK; // (cannot happen below 2^31 edges)
+    }
+    off[(size_t)T * T] = (uint32_t)at;
+    HIPCHK(c, hipMalloc(&c->d_colt, nnz * 4));
+    HIPCHK(c, hipMalloc(&c->d_team_off, off.size() * 4));
+    HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), nnz * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_team_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    c->team_T = T; c->team_R = R; c->team_cap = at;
+    return FORA_OK;
+}
+
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
+    if (int rt = ensure_team(c)) return rt;
     WsPlan p = plan_workspace(c, omega_hint, 1024); // bytes per slot hardly depend on the slot count (sub-bucket rounding)
     const uint64_t n = (uint64_t)c->n;
     // an existing workspace with the same layout is kept if it has enough slots: as many as the call can use, or as
@@ -384,6 +459,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     auto keepable = [&](int need) {
         if (c->B <= 0 || c->B < need) return false;
         const WsPlan pe = plan_workspace(c, omega_hint, c->B);
+        if ((c->team_T != 0) != (c->d_team_msg != nullptr)) return false;
         return c->binned == pe.binned && c->pbins == pe.pbins && c->seg_cap * sizeof(PushSeg) >= (uint64_t)c->B * pe.scratch &&
                c->wit_cap >= pe.wits && c->bk_cap == pe.bk_cap && c->sub == pe.sub;
     };
@@ -433,6 +509,19 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMalloc(&c->d_dflag, 2 * (size_t)B * p.nbins * 4));
         if (c->opt_.defer > 0) HIPCHK(c, hipMalloc(&c->d_dl, 2 * slab * 4)); // k_push_tail's deferred lists: only with the option (changing it re-plans the workspace)
         if (c->hubs && c->hub_shift == bin_shift(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
+        if (c->team_T) { // team push: message buffers of every team (two parities), bucket counts, control words
+            const uint32_t T = c->team_T;
+            uint32_t nteams = std::max<uint32_t>(1, (uint32_t)c->prop.multiProcessorCount / T);
+            if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
+            size_t fr = 0, tot = 0;
+            HIPCHK(c, hipMemGetInfo(&fr, &tot));
+            const uint64_t per_team = 2 * c->team_cap * 8;
+            nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
+            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * per_team));
+            HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
+            HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 4 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
+            c->team_n = nteams;
+        }
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
         HIPCHK(c, hipMalloc(&c->d_wl[1], slab * 8));
@@ -548,6 +637,7 @@ void ev_collect(fora_ctx *c) { // call after the stream is idle
         case 6: c->timing.push_accum_ms += ms; c->timing.push_accum_launches++; break;
         case 7: c->timing.walk_accum_ms += ms; break;
         case 9: c->timing.push_tail_ms += ms; c->timing.push_tail_launches++; break;
+        case 10: c->timing.push_team_ms += ms; c->timing.push_team_launches++; break;
         case 8: c->timing.push_accum_ms += ms; break; // k_round_sweep: part of the level's accumulate time, not a launch of its own in the counts
         }
     }
@@ -560,9 +650,10 @@ int check_dev_err(fora_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bucket_overflow = (e & ERR_BUCKET_OVERFLOW) != 0;
     if (e) {
-        char buf[96];
+        char buf[256];
         snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x%s)", e,
-                 (e & ERR_BUCKET_OVERFLOW) ? ": message buckets and their overflow list are full, raise FORA_HIP_BKCAP" : "");
+                 (e & ERR_TEAM_TIMEOUT) ? ": a team of k_push_team waited 3 s for a member (workgroups not co-resident?); FORA_HIP_TEAM=0 selects the bucketed push"
+                 : (e & ERR_BUCKET_OVERFLOW) ? ": message buckets and their overflow list are full, raise FORA_HIP_BKCAP" : "");
         return fail(c, FORA_E_OVERFLOW, buf);
     }
     return FORA_OK;
@@ -698,6 +789,52 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
         if (e != hipSuccess) rc = fail(c, FORA_E_HIP, std::string("push launch: ") + hipGetErrorString(e));
     }
     return rc;
+}
+
+// Team push of a batch (fora_team.h): ONE launch runs every slot's push down to a small frontier with the residue
+// resident in LDS, k_push_tail finishes the slots.  Nothing here waits for the device.
+static bool use_team(const fora_ctx *c, const Dev &d) {
+    return c->team_T && c->d_team_msg && c->binned && !d.wide && !c->balanced && d.rounds <= 1 && d.defer_k == 0 && c->opt_.team == 1;
+}
+int run_push_team(fora_ctx *c, const Dev &d) {
+    const uint32_t T = c->team_T, nteams = c->team_n;
+    TeamDev a{};
+    a.n = d.n; a.nq = d.nq; a.rowinfo = d.rowinfo; a.row_ptr = d.row_ptr; a.deg = d.deg; a.src = d.src;
+    a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
+    a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
+    a.T = T; a.R = c->team_R; a.nteams = nteams; a.nblk = (uint32_t)(((uint64_t)c->n + 63) / 64);
+    a.colt = c->d_colt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.cnt = c->d_team_cnt;
+    a.ctl = c->d_team_ctl;
+    a.sync = (unsigned long long *)(c->d_team_ctl + 64);
+    a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 4 * 16 * 2;
+    // frontier size of a slot at which k_push_tail (one workgroup per slot, global atomics) takes over; 0: never
+    const int64_t tail_auto = 4096;
+    a.tail_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_tail < 0 ? tail_auto : c->opt_.team_tail, 0), 0x7FFFFFFF);
+    if (c->opt_.tail == 0) a.tail_max = 0; // `tail` 0 keeps k_push_tail out of every path (tests)
+    a.tail_always = c->opt_.tail_always == 1 ? 1u : 0u;
+    const uint32_t grid = nteams * T;
+    a.xcd = (c->opt_.team_xcd == 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? 1u : 0u;
+    a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
+    const size_t lds = (size_t)a.R * 8;
+    if (!c->team_attr) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TEAM_R_CAP * 8)));
+        c->team_attr = true;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 4 * 16 * 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(a.slot_seq, 0xFF, (size_t)nteams * ((size_t)d.nq + 2) * 4, c->stream));
+    int h = ev_begin(c, 10);
+    hipLaunchKernelGGL(k_push_team, dim3(grid), dim3(TEAM_THREADS), lds, c->stream, a);
+    ev_end(c, h);
+    c->timing.levels++;
+    if (a.tail_max) {
+        h = ev_begin(c, 9);
+        hipLaunchKernelGGL(k_push_tail, dim3(d.nq), dim3(TAIL_THREADS), 0, c->stream, d, 0, 0);
+        ev_end(c, h);
+        c->timing.levels++;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("team push launch: ") + hipGetErrorString(e));
+    return FORA_OK;
 }
 
 // k_topk_select over the slabs of `ds.ppr`; large graphs first compact each slot's non-zero entries (in id order, so
@@ -889,10 +1026,11 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
     } else {
         if (c->binned) d.rounds = (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.rounds, 1), 16);
         d.round_div = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.round_div, 0), 1 << 20);
+        const bool team = use_team(c, d);
         h = ev_begin(c, 4);
-        hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 0);
+        hipLaunchKernelGGL(k_init_batch, dim3((nq + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, team ? 3 : 0);
         ev_end(c, h);
-        rc = run_push_levels(c, d);
+        rc = team ? run_push_team(c, d) : run_push_levels(c, d);
         d.rounds = 1;
     }
     if (rc) return rc;
@@ -974,6 +1112,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;

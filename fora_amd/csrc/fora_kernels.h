@@ -487,7 +487,7 @@ __device__ __forceinline__ uint64_t walk_count(double residual, double check_rsu
 // ------------------------------------------------------------------ init
 // residue[s] = 1, frontier = {s} (algo.h:969-978); dangling source: reserve[s] = 1 (algo.h:961-965)
 // mode 0: query, 1: top-k (round frontier built by k_topk_frontier), 2: power iteration (no dangling-source
-// short cut: query.h:1192-1224 iterates it like any other node)
+// short cut: query.h:1192-1224 iterates it like any other node), 3: query through k_push_team
 __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
     int q = blockIdx.x * BLOCK + threadIdx.x;
     if (q >= d.nq) return;
@@ -501,6 +501,8 @@ __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
         z.dangling_source = 1;
     } else if (mode == 1) {
         d.residue[a] = FIX_ONE;
+    } else if (mode == 3) {
+        // team push (fora_team.h): the source's owner sets its residue in LDS
     } else if (d.binned) {
         // bucketed push: a frontier entry is (node, residue taken from it); k_pushq_bin of level 0 pops it
         d.fl[0][(uint64_t)q * d.n] = s;

@@ -94,6 +94,8 @@ typedef struct {
     uint64_t idx_hits;      /* walks served from the index (num_hit_idx, algo.h:39) */
     double push_tail_ms;    /* k_push_tail launches (they finish the push once every frontier is small) */
     uint64_t push_tail_launches;
+    double push_team_ms;    /* k_push_team launches (graphs of the narrow layout: the whole push above the tail, one launch per batch) */
+    uint64_t push_team_launches;
 } fora_timing;
 
 /* ---- lifecycle ---------------------------------------------------------- */

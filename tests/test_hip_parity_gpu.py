@@ -164,6 +164,7 @@ def test_hub_preaggregation_bit_exact(engine, oracle, small_dangling, hubs, hub_
         engine.set_option("hubs", hubs)
     engine.set_option("hub_min", hub_min)
     engine.set_option("tail", 0)  # every level through the bucketed kernels
+    engine.set_option("team", 0)  # ... not through k_push_team
     try:
         rmax, omega = _load(engine, g, epsilon=0.5)
         srcs = np.concatenate([pick_sources(g, 6, 91), pick_sources(g, 1, 92, want_dangling=True)])
@@ -393,6 +394,7 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     # the bucketed levels are what these modes are about: keep k_push_tail (which takes over once every frontier is
     # small -- on a 32 k-node graph almost at once) out of them, except where it is the subject
     engine.set_option("tail", 100000000 if mode.startswith("tail") else 0)
+    engine.set_option("team", 0)  # the team push has its own test (test_team_push_bit_exact)
     if mode.startswith("tail"):
         engine.set_option("tail_always", 1)
     if mode == "tail_wide_multipass":
@@ -428,6 +430,43 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
         engine.clear_index()
     engine.reset_options()
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
+
+
+@pytest.mark.parametrize("size,tail,xcd,tmax", [(0, 0, 1, 0), (0, -1, 1, 0), (4, 0, 1, 0), (4, 64, 0, 0), (16, 300, 1, 0), (32, 0, 1, 0),
+                                                (32, 2000, 0, 0), (1, 16, 1, 3), (8, 1, 1, 1)])
+@pytest.mark.parametrize("gname", ["small_dangling", "small"])
+def test_team_push_bit_exact(engine, oracle, request, gname, size, tail, xcd, tmax):
+    """k_push_team (fora_team.h): the residue of a slot stays in the LDS of a team of workgroups for the whole push; levels
+    are the twin's.  Team sizes 1 ... 32 (option team_size; 0 = the fewest members whose LDS holds the graph), the
+    hand-over to k_push_tail at several frontier sizes (team_tail; 0 = the team runs the push to its end), both placements
+    of the members (team_xcd) and fewer teams than slots (team_max) all give the twin's bits."""
+    g = request.getfixturevalue(gname)
+    engine.set_option("team", 1)
+    engine.set_option("team_size", size)
+    engine.set_option("team_xcd", xcd)
+    engine.set_option("team_max", tmax)
+    if tail >= 0:
+        engine.set_option("team_tail", tail)
+        engine.set_option("tail_always", 1)  # hand over as soon as the frontier is that small, also while it is still growing
+    try:
+        rmax, omega = _load(engine, g, epsilon=0.5)
+        srcs = np.concatenate([pick_sources(g, 9, 151), pick_sources(g, 2, 152, want_dangling=True)])
+        engine.reset_timing()
+        rsv, res, st = engine.push(srcs)
+        tm = engine.timing()
+        assert tm["push_team_launches"] >= 1 and tm["push_expand_launches"] == 0  # the team kernel ran, the bucketed ones did not
+        for i, s in enumerate(srcs):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+            assert st[i]["rsum_fix"] == t["rsum_fix"]
+        ppr, _, stq = engine.query_fix(srcs[:4], want_residue=False)
+        for i in range(4):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+            assert (ppr[i] == want).all() and stq[i]["n_walks"] == wst["n_walks"]
+    finally:
+        engine.reset_options()
+        engine.query_fix(srcs[:1])
 
 
 @pytest.mark.parametrize("rounds,div", [(1, 0), (2, 0), (3, 0), (5, 0), (2, 4), (2, 2), (3, 4), (4, 1), (3, 1000000)])

@@ -39,7 +39,8 @@ def child(args):
     lv = max(1, tm["push_expand_launches"])
     out = {"lib": os.path.basename(os.environ.get("FORA_HIP_LIB", "libfora_hip.so")),
            "bin_ms": tm["push_expand_ms"] / R, "accum_ms": tm["push_accum_ms"] / R,
-           "tail_ms": tm["push_tail_ms"] / R, "push_ms": (tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_pop_ms"] + tm["push_tail_ms"]) / R,
+           "tail_ms": tm["push_tail_ms"] / R, "team_ms": tm["push_team_ms"] / R,
+           "push_ms": (tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_pop_ms"] + tm["push_tail_ms"] + tm["push_team_ms"]) / R,
            "bin_avg": tm["push_expand_ms"] / lv, "accum_avg": tm["push_accum_ms"] / max(1, tm["push_accum_launches"]),
            "launches": lv / R, "walk_alloc_ms": tm["walk_alloc_ms"] / R, "walk_ms": tm["walk_ms"] / R,
            "walk_accum_ms": tm["walk_accum_ms"] / R, "other_ms": tm["other_ms"] / R, "batch_ms": tm["batch_ms"] / R,
