@@ -115,7 +115,8 @@ struct fora_ctx {
     uint32_t team_T = 0, team_R = 0;
     uint64_t team_cap = 0;           // message slots per (team, parity)
     // ... and its workspace
-    uint64_t *d_team_msg = nullptr;
+    uint32_t *d_team_msg = nullptr;
+    uint64_t *d_team_inct = nullptr;
     uint32_t *d_team_cnt = nullptr, *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
     uint32_t team_n = 0;             // teams of a launch
     bool team_attr = false;          // dynamic LDS limit of k_push_team raised
@@ -249,7 +250,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
-    dfree(c->d_team_msg); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
+    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -431,13 +432,12 @@ int ensure_team(fora_ctx *c) {
             pair[(size_t)s * T + dd]++;
         }
     }
-    // bucket (s -> d): one message per edge, a second word for increments of 2^48 and more (at most 2^14 of them fit the
-    // unit mass), the dangling mass of the level (two words); whole 128-byte lines
+    // bucket (s -> d): one 4-byte message per edge + the dangling mass of the level; whole 64-byte lines
     std::vector<uint32_t> off((size_t)T * T + 1, 0);
     uint64_t at = 0;
     for (size_t i = 0; i < (size_t)T * T; i++) {
         off[i] = (uint32_t)at;
-        at += (pair[i] + std::min<uint64_t>(pair[i], 16384) + 2 + 15) & ~15ull;
+        at += (pair[i] + 1 + 15) & ~15ull;
         if (at >= (1ull << 32)) return FORA_OK; // (cannot happen below 2^31 edges)
     }
     off[(size_t)T * T] = (uint32_t)at;
@@ -515,9 +515,10 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            const uint64_t per_team = 2 * c->team_cap * 8;
+            const uint64_t per_team = 2 * c->team_cap * 4 + 2 * (uint64_t)T * (c->team_R + 64) * 8;
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
-            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * per_team));
+            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
+            HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
             HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 4 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
@@ -803,7 +804,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams; a.nblk = (uint32_t)(((uint64_t)c->n + 63) / 64);
-    a.colt = c->d_colt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.cnt = c->d_team_cnt;
+    a.colt = c->d_colt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 4 * 16 * 2;
@@ -814,6 +815,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.tail_always = c->opt_.tail_always == 1 ? 1u : 0u;
     const uint32_t grid = nteams * T;
     a.xcd = (c->opt_.team_xcd == 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? 1u : 0u;
+    a.stamps = c->d_stamps;
     a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
     const size_t lds = (size_t)a.R * 8;
     if (!c->team_attr) {

@@ -5,28 +5,30 @@
 // residue HBM -> LDS sum -> HBM every level: at the mid-size levels of a ws-sized query that rewrite of the slot's slab
 // is most of the bytes the pair moves.  Here a TEAM of T workgroups, one per CU, owns a slot from its
 // first level to (nearly) its last: member c keeps the residue of the nodes it owns in LDS (64-node blocks dealt
-// round-robin: owner(v) = (v >> 6) % T, R = 64 * ceil(blocks / T) <= 17 856 nodes = 140 KB of u64), and a level is
+// round-robin: owner(v) = (v >> 6) % T, R = 64 * ceil(blocks / T) <= 19 072 nodes = 149 KB of u64), and a level is
 //
-//   consume   the 8-byte messages the T members wrote for me in the previous level: ds_add_u64 into my residue
+//   consume   the 4-byte messages the T members wrote for me in the previous level: ds_add_u64 into my residue
 //   sweep     my R residue words against their thresholds (algo.h:1012): whoever is at or over it is this level's
 //             frontier -- after a level's pops every residue is under its threshold, so "crossed during the level" and
 //             "is at or over it now" are the same set
-//   pop+emit  batches of up to 1024 frontier nodes: residue -> reserve + increment (algo.h:983-1002, one lane per node),
-//             then their out-edges from a copy of col that names every target as (owner, local id): one message
-//             local | increment << 16 into the exact-capacity bucket (me -> owner), place taken from an LDS counter
+//   pop+emit  every wave on its own, 64 frontier nodes at a time: residue -> reserve + increment (algo.h:983-1002, one
+//             lane per node), then their out-edges from a copy of col that names every target as (owner, local id): one
+//             message into the exact-capacity bucket (me -> owner), place taken from an LDS counter
 //   barrier   ONE device-scope barrier of the team per level (arrive = atomic add of 2^32 + my pops on a word that
 //             rotates over four; the sum of the pops is the level's frontier size, read by every member)
 //
 // No residue slab traffic, no frontier lists, no launches, no host round trips per level.  A bucket (s -> d) can never
 // overflow: a level relaxes every edge at most once, so its capacity is the number of edges from s's nodes to d's
-// (+ the few two-word messages, see below), counted when the graph is loaded.  Once a slot's frontier is small (and has
+// (+ one for the level's dangling mass), counted when the graph is loaded.  Once a slot's frontier is small (and has
 // been large), the members write their residue ranges to the slot's slab and the crossing nodes as (node, residue taken)
 // entries to its frontier list: k_push_tail finishes all slots of the batch in one launch, as it does for the bucketed
 // levels.  Same level-synchronous schedule, integer adds: bit-identical to the bucketed path and to oracle/fora_twin.c.
 //
-// Message word: local target (15 bits) | big (bit 15) | value << 16.  An increment of 2^48 or more (the first two or
-// three levels; at most 2^14 of them fit the unit mass) travels as two words: (inc >> 14) with `big` set and
-// (inc & 0x3fff) without.
+// Message word (4 bytes): local target (15 bits) | entry << 15, where `entry` names the popped node in the producer's
+// increment table of the level (one 8-byte word per pop, written once, coalesced; the consumer gathers it from L2 --
+// a bucket's messages follow the producer's pop order, so neighbouring lanes gather neighbouring entries).  First
+// version: 8-byte messages with the increment inline -- 67 GB written and 67 GB read per 1000 ws queries, and both the
+// consume and the emit phase ran at the memory system's rate.
 #pragma once
 #include "fora_kernels.h"
 
@@ -36,14 +38,15 @@ constexpr int TEAM_MAX = 32;                  // members of a team (5 bits of a 
 constexpr int TEAM_LBITS = 15;                // bits of a local id
 constexpr int TEAM_THREADS = 1024;            // one workgroup per CU
 constexpr int TEAM_NW = TEAM_THREADS / 64;
-constexpr int TEAM_BATCH = 1024;              // frontier nodes popped per batch (one per thread)
-constexpr int TEAM_NIT = 18;                  // sweep iterations at most: R <= 18 * 1024
 constexpr uint32_t TEAM_R_CAP = 17792;        // local ids per member at most: 8 * R + the static LDS below <= 160 KiB
 #ifndef FORA_TEAM_EPT
-#define FORA_TEAM_EPT 8
+#define FORA_TEAM_EPT 4
+#endif
+#ifndef FORA_TEAM_CU
+#define FORA_TEAM_CU 4
 #endif
 constexpr int TEAM_EPT = FORA_TEAM_EPT;       // consecutive edges a lane gathers per chunk
-constexpr uint32_t TEAM_BIG = 1u << 15;
+constexpr uint32_t TEAM_LMASK = (1u << TEAM_LBITS) - 1u;
 constexpr uint32_t TEAM_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t ERR_TEAM_TIMEOUT = 16, ERR_TEAM_CAP = 32;
 
@@ -65,7 +68,8 @@ struct TeamDev {
     uint32_t T, R, nteams, nblk;   // members per team; local ids per member; teams of the launch; 64-node blocks of the graph
     const uint32_t *colt;          // [nnz] owner << 15 | local id of every edge target, rows as in col
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
-    uint64_t *msg;                 // [nteams][2][off[T * T]]
+    uint32_t *msg;                 // [nteams][2][off[T * T]]
+    uint64_t *inct;                // [nteams][2][T][R + 64] increment tables: entry e of member s = the increment of its e-th pop of the level
     uint32_t *cnt;                 // [nteams][2][T * T] messages in bucket (s -> d) this level
     unsigned long long *sync;      // [nteams][4][16] barrier words, one 128-byte line each
     uint32_t *slot_seq;            // [nteams][nq + 2] slot taken by the team in its k-th turn (TEAM_EMPTY: not yet)
@@ -73,6 +77,7 @@ struct TeamDev {
     uint32_t tail_max;             // hand the slot to k_push_tail once its frontier is at most this (and has been larger); 0: never
     uint32_t tail_always;          // tests: do not wait for the frontier to have been larger
     uint32_t xcd;                  // != 0: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
+    unsigned long long *stamps;    // diagnostic builds (-DFORA_STAMPS): cycles per phase of thread 0, summed over workgroups, [0..7]
     uint64_t timeout_ticks;        // wall_clock64 ticks (100 MHz) a member waits for its team before it gives up
 };
 
@@ -102,22 +107,42 @@ __device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE 
     }
 }
 
+#ifdef FORA_STAMPS
+#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TSTAMP(k) do { const long long n_ = clock64(); ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
+#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (ts_a_[i_]) atomicAdd(&a.stamps[i_], ts_a_[i_]); } while (0)
+#else
+#define TSTAMP_DECL
+#define TSTAMP(k) do {} while (0)
+#define TSTAMP_FLUSH() do {} while (0)
+#endif
 // grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * R bytes.
+//
+// Inside a level nothing but the consume -> sweep and the emit -> barrier seams is a workgroup barrier: every WAVE sweeps
+// 64-id groups (drawn from a shared counter), collects the crossing nodes in a wave-private list and pops / emits them 128
+// at a time on its own (prefix sums by wave scan, in a wave-private LDS area), so the sixteen waves of a member overlap each
+// other's memory round trips and every round trip carries two pops or eight edges per lane.  (First version: block-wide batches of 1024 pops between barriers --
+// one exposed HBM round trip per batch, 46 % of the kernel's cycles.)  Rows of more than TEAM_HEAVY edges are parked in a
+// small list and relaxed by the whole workgroup afterwards, consecutive lanes on consecutive edges.
+constexpr uint32_t TEAM_HEAVY = 1024;
+constexpr int TEAM_NHEAVY = 128;
+constexpr int TEAM_WB = 128;          // nodes a wave pops per batch: two per lane, their loads in flight together
+constexpr int TEAM_MAXGROUPS = 304;  // 64-id groups of a member at most (R <= 19 456)
 __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
-    extern __shared__ uint64_t res[];                   // [R] residue of my nodes
-    __shared__ uint64_t s_inc[TEAM_BATCH];              // increment of batch entry i
-    __shared__ uint32_t s_ebeg[TEAM_BATCH];             // its first edge
-    __shared__ uint32_t s_pref[TEAM_BATCH + 1];         // exclusive prefix of the batch's out-degrees
-    __shared__ uint16_t s_list[TEAM_BATCH];             // local ids of the batch
-    __shared__ uint32_t s_cell[TEAM_NIT * TEAM_NW + 1]; // crossing nodes per (sweep iteration, wave), then their exclusive prefix
-    __shared__ uint32_t s_w[TEAM_NW];
+    extern __shared__ uint64_t res[];                        // [R] residue of my nodes
+    __shared__ uint32_t w_pref[TEAM_NW][TEAM_WB + 1];        // per wave: exclusive prefix of the out-degrees of the nodes of its batch
+    __shared__ uint32_t w_area[TEAM_NW][TEAM_WB];            // per wave: local ids (u16) of crossing nodes waiting to be popped; over them, once read, the first edge of every node of the batch
+    __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
+    __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX], s_mcap[TEAM_MAX]; // messages I have put into bucket (me -> d) this level; its first slot; its size
-    __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_coff[TEAM_MAX]; // prefix of the messages waiting for me per source; bucket (s -> me)
-    __shared__ uint32_t s_slot, s_F, s_ok, s_base;
+    __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 64-message segments; bucket (s -> me)
+    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext;
+    const uint32_t tstride = a.R + 64; // entries of one increment table
     __shared__ unsigned long long s_dang, s_acc[3];
 
     const uint32_t T = a.T, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t team, me;
     if (a.xcd) { // blocks b and b + 8 share an XCD (observed, not promised): a team = T blocks of one residue class
         const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3; // per: blocks per class, a multiple of T
@@ -134,6 +159,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
     for (uint32_t l = tid; l < R; l += TEAM_THREADS) res[l] = 0;
     if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_mcap[tid] = a.off[me * T + tid + 1] - a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
     __syncthreads();
+    TSTAMP_DECL
     uint32_t g = 0; // barriers this team has passed: message / count buffers by g & 1, barrier words by g & 3
 
     for (uint32_t turn = 0;; turn++) {
@@ -152,6 +178,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
         __syncthreads();
         if (!s_ok) return;
         const uint32_t q = s_slot;
+        TSTAMP(7);
         if (q >= (uint32_t)a.nq) break;
         const uint32_t src = (uint32_t)a.src[q];
         if (a.deg[src] == 0) continue; // dangling source: k_init_batch has written the whole answer (algo.h:961-965)
@@ -165,51 +192,62 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             // ================= consume: the messages of the previous level that are addressed to me
             if (L > 0) {
                 const uint32_t *cin = a.cnt + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * T;
-                const uint64_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
+                const uint32_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
+                const uint64_t *tin = a.inct + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * tstride;
                 if (tid < 64) {
-                    uint32_t c = (uint32_t)lane < T ? cin[(uint32_t)lane * T + me] : 0u;
-                    uint32_t tot;
+                    const uint32_t c = (uint32_t)lane < T ? cin[(uint32_t)lane * T + me] : 0u;
+                    uint32_t tot, tots;
                     const uint32_t ex = wave_excl_scan(c, tot);
-                    if ((uint32_t)lane < T) s_cpre[lane] = ex;
-                    if (lane == 0) s_cpre[T] = tot;
+                    const uint32_t exs = wave_excl_scan((c + 127u) >> 7, tots);
+                    if ((uint32_t)lane < T) { s_cpre[lane] = ex; s_cseg[lane] = exs; }
+                    if (lane == 0) { s_cpre[T] = tot; s_cseg[T] = tots; }
                 }
                 __syncthreads();
-                const uint32_t total = s_cpre[T];
-                constexpr int CU = 4; // loads in flight per lane
-                for (uint32_t i0 = 0; i0 < total; i0 += TEAM_THREADS * CU) {
-                    uint64_t m[CU];
+                // a wave takes 128-message segments wid, wid + 16, ... (two messages per lane), CU of them per trip: all
+                // message loads in flight together, then all increment gathers
+                const uint32_t nseg = s_cseg[T];
+                constexpr int CU = FORA_TEAM_CU;
+                for (uint32_t j0 = wid; j0 < nseg; j0 += TEAM_NW * CU) {
+                    uint2 m[CU];
+                    uint32_t srcm[CU], left[CU];
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
-                        const uint32_t i = i0 + k * TEAM_THREADS + tid;
-                        const uint32_t ic = i < total ? i : 0u;
-                        uint32_t lo = 0, hi = T; // largest lo with s_cpre[lo] <= ic
+                        const uint32_t j = j0 + k * TEAM_NW;
+                        const uint32_t jc = j < nseg ? j : 0u;
+                        uint32_t lo = 0, hi = T; // largest lo with s_cseg[lo] <= jc (wave-uniform)
 #pragma unroll
                         for (int it = 0; it < 5; it++) {
                             const uint32_t mid = (lo + hi) >> 1;
-                            if (hi - lo > 1) { if (s_cpre[mid] <= ic) lo = mid; else hi = mid; }
+                            if (hi - lo > 1) { if (s_cseg[mid] <= jc) lo = mid; else hi = mid; }
                         }
-                        m[k] = total ? min_[(uint64_t)s_coff[lo] + (ic - s_cpre[lo])] : 0ull;
+                        const uint32_t idx = ((jc - s_cseg[lo]) << 7) + 2u * lane;
+                        const uint32_t n_s = s_cpre[lo + 1] - s_cpre[lo];
+                        left[k] = (j < nseg && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
+                        srcm[k] = lo;
+                        m[k] = *(const uint2 *)(min_ + (uint64_t)s_coff[lo] + (left[k] ? idx : 0u)); // (buckets hold a multiple of 16 words)
+                    }
+                    uint64_t va[CU], vb[CU];
+#pragma unroll
+                    for (int k = 0; k < CU; k++) {
+                        const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
+                        va[k] = tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u];
+                        vb[k] = tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u];
                     }
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
-                        const uint32_t i = i0 + k * TEAM_THREADS + tid;
-                        if (i < total) {
-                            uint64_t val = m[k] >> 16;
-                            if ((uint32_t)m[k] & TEAM_BIG) val <<= 14;
-                            if (val) atomicAdd((unsigned long long *)&res[(uint32_t)m[k] & (TEAM_BIG - 1u)], (unsigned long long)val);
-                        }
+                        if (left[k] && va[k]) atomicAdd((unsigned long long *)&res[m[k].x & TEAM_LMASK], (unsigned long long)va[k]);
+                        if (left[k] > 1 && vb[k]) atomicAdd((unsigned long long *)&res[m[k].y & TEAM_LMASK], (unsigned long long)vb[k]);
                     }
                 }
                 __syncthreads();
+                TSTAMP(0);
             }
-            // ================= sweep: who is at or over the threshold (algo.h:1012)
-            uint32_t crossmask = 0, ncross = 0;
-            if (L == 0) { // the source is popped whatever its threshold (algo.h:969-978)
-                if (tid == 0) { s_cell[0] = 0; s_cell[TEAM_NIT * TEAM_NW] = me == src_owner ? 1u : 0u; }
-                if (me == src_owner && tid == 0) { res[src_local] = FIX_ONE; }
-                __syncthreads();
-                ncross = s_cell[TEAM_NIT * TEAM_NW];
-            } else {
+            // ================= sweep: who is at or over the threshold (algo.h:1012).  Thread t looks at local ids
+            // it * 1024 + t: wave w owns the 64-id groups it * 16 + w.
+            uint32_t crossmask = 0;
+            if (tid < TEAM_MAX) s_fill[tid] = 0;
+            if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; }
+            if (L > 0) {
                 constexpr int SG = 6; // iterations whose loads are in flight together
                 for (uint32_t g0 = 0; g0 < nit; g0 += SG) {
                     uint64_t r[SG];
@@ -226,167 +264,211 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                     }
 #pragma unroll
                     for (int k = 0; k < SG; k++) {
-                        const uint32_t it = g0 + k;
-                        if (it < nit) { // wave-uniform
-                            const bool c = r[k] && r[k] >= node_thr(a.t1, dg[k]);
+                        const bool c = r[k] && r[k] >= node_thr(a.t1, dg[k]);
+                        if (c) crossmask |= 1u << (g0 + k);
+                        if (g0 + k < nit) { // wave-uniform; group (it, wave) = local ids (it * 16 + wave) * 64 ...
                             const unsigned long long mk = __ballot(c);
-                            if (lane == 0) s_cell[it * TEAM_NW + wid] = (uint32_t)__popcll(mk);
-                            if (c) crossmask |= 1u << it;
+                            if (lane == 0) s_gmask[(g0 + k) * TEAM_NW + wid] = mk;
                         }
                     }
                 }
-                __syncthreads();
-                if (wid == 0) { // exclusive prefix over the (iteration, wave) cells
-                    constexpr int CPL = (TEAM_NIT * TEAM_NW + 63) / 64;
-                    const uint32_t cells = nit * TEAM_NW;
-                    uint32_t cc[CPL], sum = 0;
-#pragma unroll
-                    for (int j = 0; j < CPL; j++) { cc[j] = (uint32_t)(CPL * lane + j) < cells ? s_cell[CPL * lane + j] : 0u; sum += cc[j]; }
-                    uint32_t tot;
-                    uint32_t ex = wave_excl_scan(sum, tot);
-#pragma unroll
-                    for (int j = 0; j < CPL; j++) { if ((uint32_t)(CPL * lane + j) < cells) s_cell[CPL * lane + j] = ex; ex += cc[j]; }
-                    if (lane == 0) s_cell[TEAM_NIT * TEAM_NW] = tot;
-                }
-                __syncthreads();
-                ncross = s_cell[TEAM_NIT * TEAM_NW];
+            } else if (me == src_owner && wid == 0) { // the source is popped whatever its threshold (algo.h:969-978)
+                if (lane == 0) res[src_local] = FIX_ONE;
             }
+            TSTAMP(1);
+            __syncthreads(); // s_fill / s_dang / counters are zeroed; (level 0) the source's residue is in place
             if (final_round) {
                 // ================= hand-over: crossing nodes -> (node, residue taken) entries of the slot's frontier list
                 // (k_push_tail pops them, see k_accum), then my residue range -> the slot's slab
-                if (ncross) {
-                    if (tid == 0) s_base = atomicAdd(&a.fl_count0[q * CSTRIDE], ncross);
-                    __syncthreads();
-                    const uint32_t base = s_base;
+                uint32_t mine = 0;
+                for (uint32_t it = 0; it < nit; it++) mine += (uint32_t)__popcll(__ballot((crossmask >> it) & 1u));
+                if (mine) { // wave-uniform
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&a.fl_count0[q * CSTRIDE], mine);
+                    base = __shfl(base, 0);
                     for (uint32_t it = 0; it < nit; it++) {
-                        {
-                            const bool c = (crossmask >> it) & 1u;
-                            const unsigned long long mk = __ballot(c);
-                            if (c) {
-                                const uint32_t l = it * TEAM_THREADS + tid;
-                                const uint32_t pos = base + s_cell[it * TEAM_NW + wid] + (uint32_t)__popcll(mk & ((1ull << lane) - 1));
-                                if (pos < (uint32_t)a.n) {
-                                    a.fl0[slab + pos] = team_node(l, me, T);
-                                    a.inc_tab0[(uint64_t)q * a.segq_cap + pos] = res[l];
-                                } else atomicOr(a.err, ERR_WL_OVERFLOW);
-                                res[l] = 0;
-                            }
+                        const bool c = (crossmask >> it) & 1u;
+                        const unsigned long long mk = __ballot(c);
+                        if (c) {
+                            const uint32_t l = it * TEAM_THREADS + tid;
+                            const uint32_t pos = base + (uint32_t)__popcll(mk & lt_mask);
+                            if (pos < (uint32_t)a.n) {
+                                a.fl0[slab + pos] = team_node(l, me, T);
+                                a.inc_tab0[(uint64_t)q * a.segq_cap + pos] = res[l];
+                            } else atomicOr(a.err, ERR_WL_OVERFLOW);
+                            res[l] = 0;
                         }
+                        base += (uint32_t)__popcll(mk);
                     }
                 }
-                for (uint32_t l = tid; l < R; l += TEAM_THREADS) {
+                for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
                     const uint32_t v = team_node(l, me, T);
                     if (v < (uint32_t)a.n) a.residue[slab + v] = res[l];
                     res[l] = 0;
                 }
+                TSTAMP(6);
                 break;
             }
-            // ================= pop + emit, a batch of TEAM_BATCH frontier nodes at a time
-            uint64_t *mout = a.msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
-            if (tid < TEAM_MAX) s_fill[tid] = 0;
-            if (tid == 0) s_dang = 0;
+            // ================= pop + emit, every wave on its own.  The waves draw the level's 64-id groups from a shared
+            // counter (a group whose nodes have long rows keeps one wave busy while the others take the rest), collect the
+            // crossing nodes in a wave-private list and pop TEAM_WB of them at a time, two per lane.
+            uint32_t *mout = a.msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
+            uint64_t *tout = a.inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride; // my increment table of this level
             uint64_t my_dang = 0;
-            for (uint32_t b0 = 0; b0 < ncross; b0 += TEAM_BATCH) {
-                const uint32_t nb = min((uint32_t)TEAM_BATCH, ncross - b0);
-                __syncthreads(); // the previous batch is done with the lists (and s_fill / s_dang are zeroed)
-                if (L == 0) {
-                    if (tid == 0) s_list[0] = (uint16_t)src_local;
-                } else {
-                    for (uint32_t it = 0; it < nit; it++) {
-                        {
-                            const bool c = (crossmask >> it) & 1u;
-                            const unsigned long long mk = __ballot(c);
-                            if (c) {
-                                const uint32_t rank = s_cell[it * TEAM_NW + wid] + (uint32_t)__popcll(mk & ((1ull << lane) - 1)) - b0;
-                                if (rank < (uint32_t)TEAM_BATCH) s_list[rank] = (uint16_t)(it * TEAM_THREADS + tid);
-                            }
+            {
+                uint16_t *list = (uint16_t *)w_area[wid]; // [2 * TEAM_WB] entries fit the area; TEAM_WB + 63 are used at most
+                uint32_t *ebegs = w_area[wid];
+                uint32_t *pref = w_pref[wid];
+                const uint32_t ngroups = L == 0 ? 0u : nit * TEAM_NW;
+                uint32_t npend = 0;
+                bool drained = false;
+                if (L == 0) { drained = true; if (me == src_owner && wid == 0) { if (lane == 0) list[0] = (uint16_t)src_local; npend = 1; } }
+                for (;;) {
+                    while (!drained && npend < (uint32_t)TEAM_WB) { // draw groups until a batch is full
+                        uint32_t gi = 0;
+                        if (lane == 0) gi = atomicAdd(&s_gnext, 1u);
+                        gi = (uint32_t)__shfl((int)gi, 0);
+                        if (gi >= ngroups) { drained = true; break; }
+                        const unsigned long long mk = s_gmask[gi];
+                        if (!mk) continue;
+                        if ((mk >> lane) & 1ull) list[npend + (uint32_t)__popcll(mk & lt_mask)] = (uint16_t)(gi * 64 + lane);
+                        npend += (uint32_t)__popcll(mk);
+                    }
+                    if (npend == 0) break;
+                    // ---- pop up to TEAM_WB nodes, two per lane: entries lane and 64 + lane (algo.h:983-1002)
+                    const uint32_t m = min(npend, (uint32_t)TEAM_WB);
+                    const uint32_t left = npend - m; // < 64: they wait in a register while the area holds the batch's row starts
+                    const uint32_t l0 = list[lane], l1 = list[64 + lane];
+                    const uint16_t keep = list[TEAM_WB + (lane < 63 ? lane : 63)];
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                    uint32_t ebase = 0; // my entries of the level's increment table: ebase + entry
+                    if (lane == 0) ebase = atomicAdd(&s_ncross, m);
+                    ebase = (uint32_t)__shfl((int)ebase, 0);
+                    const bool v0ok = (uint32_t)lane < m, v1ok = (uint32_t)lane + 64 < m;
+                    const uint32_t v0 = team_node(l0, me, T), v1 = team_node(l1, me, T);
+                    uint64_t ri0 = 0, ri1 = 0, po0 = 0, po1 = 0;
+                    if (v0ok) { ri0 = a.rowinfo[v0]; po0 = a.ppr[slab + v0]; }
+                    if (v1ok) { ri1 = a.rowinfo[v1]; po1 = a.ppr[slab + v1]; }
+                    uint32_t cnt0 = 0, cnt1 = 0;
+                    if (v0ok) {
+                        const uint64_t rr = res[l0];
+                        res[l0] = 0;                                         // algo.h:984-985
+                        const uint32_t deg = team_deg(a, ri0, v0);
+                        uint64_t rsv_add, dang;
+                        const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
+                        if (rsv_add) a.ppr[slab + v0] = po0 + rsv_add;       // algo.h:986-989 (this member owns v0)
+                        acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
+                        cnt0 = inc ? deg : 0u;
+                        if (cnt0) tout[ebase + lane] = inc;
+                        if (cnt0 > TEAM_HEAVY) { // a hub's row: relaxed by the whole workgroup after the waves' own rows
+                            const uint32_t hi = atomicAdd(&s_nheavy, 1u);
+                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + lane; h_ebeg[hi] = (uint32_t)(ri0 >> 24); h_deg[hi] = cnt0; cnt0 = 0; }
                         }
                     }
-                }
-                __syncthreads();
-                uint32_t cnt = 0;
-                if ((uint32_t)tid < nb) { // one pop per lane (algo.h:983-1002)
-                    const uint32_t l = s_list[tid];
-                    const uint32_t v = team_node(l, me, T);
-                    const uint64_t rr = res[l];
-                    res[l] = 0;                                       // algo.h:984-985
-                    const uint64_t ri = a.rowinfo[v];
-                    const uint32_t deg = team_deg(a, ri, v);
-                    const uint64_t rsv_old = a.ppr[slab + v];
-                    uint64_t rsv_add, dang;
-                    const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                    if (rsv_add) a.ppr[slab + v] = rsv_old + rsv_add; // algo.h:986-989 (this member owns v)
-                    acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
-                    s_ebeg[tid] = (uint32_t)(ri >> 24);
-                    s_inc[tid] = inc;
-                    cnt = inc ? deg : 0u;
-                }
-                uint32_t total;
-                const uint32_t pre = block_excl_scan_n<TEAM_THREADS>(cnt, s_w, total);
-                s_pref[tid] = pre;
-                if (tid == 0) s_pref[TEAM_BATCH] = total;
-                __syncthreads();
-                for (uint32_t cb = 0; cb < total; cb += TEAM_THREADS * TEAM_EPT) { // no barrier in here: the waves run free
-                    const uint32_t e0 = cb + tid * TEAM_EPT;
-                    if (e0 >= total) continue;
-                    uint32_t lo = 0, hi = TEAM_BATCH;
-#pragma unroll
-                    for (int it = 0; it < 10; it++) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= e0) lo = mid; else hi = mid;
+                    if (v1ok) {
+                        const uint64_t rr = res[l1];
+                        res[l1] = 0;
+                        const uint32_t deg = team_deg(a, ri1, v1);
+                        uint64_t rsv_add, dang;
+                        const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
+                        if (rsv_add) a.ppr[slab + v1] = po1 + rsv_add;
+                        acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
+                        cnt1 = inc ? deg : 0u;
+                        if (cnt1) tout[ebase + 64 + lane] = inc;
+                        if (cnt1 > TEAM_HEAVY) {
+                            const uint32_t hi = atomicAdd(&s_nheavy, 1u);
+                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + 64 + lane; h_ebeg[hi] = (uint32_t)(ri1 >> 24); h_deg[hi] = cnt1; cnt1 = 0; }
+                        }
                     }
-                    uint32_t w[TEAM_EPT], si[TEAM_EPT];
+                    uint32_t tot0, tot1;
+                    const uint32_t pre0 = wave_excl_scan(cnt0, tot0);
+                    const uint32_t pre1 = tot0 + wave_excl_scan(cnt1, tot1);
+                    const uint32_t total = tot0 + tot1;
+                    pref[lane] = pre0; pref[64 + lane] = pre1;
+                    if (lane == 0) pref[TEAM_WB] = total;
+                    ebegs[lane] = (uint32_t)(ri0 >> 24); ebegs[64 + lane] = (uint32_t)(ri1 >> 24);
+                    TSTAMP(2);
+                    // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows
+                    for (uint32_t cb = 0; cb < total; cb += 64 * TEAM_EPT) {
+                        const uint32_t e0 = cb + lane * TEAM_EPT;
+                        uint32_t lo = 0;
+                        if (e0 < total) {
+                            uint32_t hi = TEAM_WB;
 #pragma unroll
-                    for (int k = 0; k < TEAM_EPT; k++) {
-                        const uint32_t e = e0 + k;
-                        if (e < total) while (s_pref[lo + 1] <= e) lo++; // entries without edges
-                        si[k] = lo;
-                    }
+                            for (int s7 = 0; s7 < 7; s7++) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (pref[mid] <= e0) lo = mid; else hi = mid;
+                            }
+                        }
+                        uint32_t w[TEAM_EPT], si[TEAM_EPT];
+                        uint32_t cur = TEAM_EMPTY, eb = 0, pb = 0;
 #pragma unroll
-                    for (int k = 0; k < TEAM_EPT; k++) {
-                        const uint32_t e = e0 + k;
-                        w[k] = TEAM_EMPTY;
-                        if (e < total) w[k] = a.colt[(uint64_t)s_ebeg[si[k]] + (e - s_pref[si[k]])];
-                    }
+                        for (int k = 0; k < TEAM_EPT; k++) {
+                            const uint32_t e = e0 + k;
+                            w[k] = TEAM_EMPTY;
+                            if (e < total) {
+                                while (pref[lo + 1] <= e) lo++; // entries without edges
+                                if (lo != cur) { cur = lo; eb = ebegs[lo]; pb = pref[lo]; }
+                                w[k] = a.colt[(uint64_t)eb + (e - pb)];
+                            }
+                            si[k] = lo;
+                        }
 #pragma unroll
-                    for (int k = 0; k < TEAM_EPT; k++) {
-                        if (w[k] == TEAM_EMPTY) continue;
-                        const uint32_t dst = w[k] >> TEAM_LBITS, local = w[k] & (TEAM_BIG - 1u);
-                        const uint64_t inc = s_inc[si[k]];
-                        const bool big = (inc >> 48) != 0;
-                        const uint32_t pos = atomicAdd(&s_fill[dst], big ? 2u : 1u);
-                        uint64_t *at = mout + (uint64_t)s_moff[dst] + pos;
-                        if (pos + (big ? 2u : 1u) > s_mcap[dst]) { atomicOr(a.err, ERR_TEAM_CAP); continue; } // cannot happen: the capacity is the bucket's edge count
-                        if (!big) at[0] = (uint64_t)local | (inc << 16);
-                        else { at[0] = (uint64_t)local | TEAM_BIG | ((inc >> 14) << 16); at[1] = (uint64_t)local | ((inc & 0x3FFFull) << 16); }
+                        for (int k = 0; k < TEAM_EPT; k++) {
+                            if (w[k] == TEAM_EMPTY) continue;
+                            const uint32_t dst = w[k] >> TEAM_LBITS;
+                            const uint32_t pos = atomicAdd(&s_fill[dst], 1u);
+                            if (pos >= s_mcap[dst]) { atomicOr(a.err, ERR_TEAM_CAP); continue; } // cannot happen: the capacity is the bucket's edge count
+                            mout[(uint64_t)s_moff[dst] + pos] = (w[k] & TEAM_LMASK) | ((ebase + si[k]) << TEAM_LBITS);
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                    if ((uint32_t)lane < left) list[lane] = keep; // the waiting entries move to the front
+                    npend = left;
+                    TSTAMP(3);
                 }
             }
+            TSTAMP(2);
             // the dangling nodes' mass returns to the source within the level (algo.h:993-998): one message to its owner
             my_dang = wave_sum(my_dang);
             if (lane == 0 && my_dang) atomicAdd(&s_dang, (unsigned long long)my_dang);
+            __syncthreads();
+            { // heavy rows: consecutive lanes on consecutive edges
+                const uint32_t nh = min(s_nheavy, (uint32_t)TEAM_NHEAVY);
+                for (uint32_t h = 0; h < nh; h++) {
+                    const uint32_t eb = h_ebeg[h], dgh = h_deg[h], ent = h_ent[h] << TEAM_LBITS;
+                    for (uint32_t e = tid; e < dgh; e += TEAM_THREADS) {
+                        const uint32_t w = a.colt[(uint64_t)eb + e];
+                        const uint32_t dst = w >> TEAM_LBITS;
+                        const uint32_t pos = atomicAdd(&s_fill[dst], 1u);
+                        if (pos >= s_mcap[dst]) { atomicOr(a.err, ERR_TEAM_CAP); continue; }
+                        mout[(uint64_t)s_moff[dst] + pos] = (w & TEAM_LMASK) | ent;
+                    }
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave's message stores have completed before the barrier
             __syncthreads();
-            if (tid == 0 && s_dang) {
-                const uint64_t dm = s_dang;
-                const bool big = (dm >> 48) != 0;
-                const uint32_t pos = s_fill[src_owner];
-                uint64_t *at = mout + (uint64_t)s_moff[src_owner] + pos;
-                if (pos + 2u > s_mcap[src_owner]) atomicOr(a.err, ERR_TEAM_CAP);
-                else if (!big) at[0] = (uint64_t)src_local | (dm << 16);
-                else { at[0] = (uint64_t)src_local | TEAM_BIG | ((dm >> 14) << 16); at[1] = (uint64_t)src_local | ((dm & 0x3FFFull) << 16); }
-                s_fill[src_owner] = pos + (big ? 2u : 1u);
+            TSTAMP(4);
+            if (tid == 0 && s_dang) { // one more table entry, one more message
+                const uint32_t ent = s_ncross, pos = s_fill[src_owner];
+                tout[ent] = s_dang;
+                if (pos >= s_mcap[src_owner]) atomicOr(a.err, ERR_TEAM_CAP);
+                else mout[(uint64_t)s_moff[src_owner] + pos] = src_local | (ent << TEAM_LBITS);
+                s_fill[src_owner] = pos + 1;
             }
             __syncthreads();
             if ((uint32_t)tid < T) (a.cnt + ((uint64_t)team * 2 + (g & 1u)) * T * T)[me * T + tid] = s_fill[tid];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            TSTAMP(4);
             // ================= the team's barrier; the level's frontier size comes with it
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 unsigned long long *wd = &sync[(g & 3u) * 16];
-                __hip_atomic_fetch_add(wd, (1ull << 32) | (unsigned long long)ncross, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(wd, (1ull << 32) | (unsigned long long)s_ncross, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long v = 0;
                 const bool ok = team_wait(a, a.err, [&] { v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (uint32_t)(v >> 32) == T; });
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -396,6 +478,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                 s_ok = ok ? 1u : 0u;
             }
             __syncthreads();
+            TSTAMP(5);
             if (!s_ok) return;
             g++;
             const uint32_t F = s_F; // nodes the team popped in this level
@@ -423,6 +506,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             if (me == 0 && nlev) atomicAdd(&s->levels, nlev);
         }
     }
+    TSTAMP_FLUSH();
 }
 
 } // namespace fora
