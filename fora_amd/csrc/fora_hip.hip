@@ -54,9 +54,12 @@ struct Tunables {
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
-    int64_t team = 1;            // 1: graphs of the narrow layout push with k_push_team (residue resident in LDS, fora_team.h); 0: the bucketed kernels (read by set_graph and at launch)
+    int64_t team = -1;           // graphs of the narrow layout push with k_push_team (residue resident in the LDS of a team of workgroups, fora_team.h): 1 always, 0 never (bucketed kernels),
+                                 // -1: when more than a fifth of the nodes are dangling -- their mass returns to the source every level and the push ends in hundreds of tiny levels, which cost
+                                 // the team a barrier each and the bucketed path a launch pair or a k_push_tail level (ws-sized R-MAT with 52 % dangling nodes, push of 1000 queries: 46.8 ms against 66.5);
+                                 // on the headline graph (no dangling nodes) the bucketed kernels are faster (75.3 ms against 81.9).  Same bits either way.
     int64_t team_size = 0;       // members per team (a power of two up to 32); 0: the fewest whose LDS holds the graph; read by set_graph
-    int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: default
+    int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096, never on graphs with more than a fifth of dangling nodes
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
     int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
@@ -111,8 +114,11 @@ struct fora_ctx {
     uint8_t *d_dg_T = nullptr;
     WalkDG dg{};
     // team push (fora_team.h): target copy of col, bucket offsets; built by set_graph for graphs of the narrow layout
-    uint32_t *d_colt = nullptr, *d_team_off = nullptr;
-    uint32_t team_T = 0, team_R = 0;
+    uint32_t *d_colt = nullptr, *d_team_off = nullptr, *d_team_n2l = nullptr, *d_team_l2n = nullptr;
+    uint16_t *d_team_deg16 = nullptr;
+    uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
+    bool team_checked = false, team_wanted = false;  // ensure_team has looked at this graph with these options
+    double dangling_frac = 0;        // share of the nodes without out-edges
     uint64_t team_cap = 0;           // message slots per (team, parity)
     // ... and its workspace
     uint32_t *d_team_msg = nullptr;
@@ -229,7 +235,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
-    dfree(c->d_colt); dfree(c->d_team_off); c->team_T = 0; c->team_R = 0; c->team_cap = 0;
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -396,40 +402,55 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 // Team push (fora_team.h): members per team for this graph (0: the graph does not take the team path), the copy of
 // col that names every target as (owner, local id) and the exact bucket capacities.  Built on first use and whenever
 // the `team` / `team_size` options ask for another shape.
-static uint32_t want_team_size(const fora_ctx *c) {
-    if (c->opt_.team != 1 || !want_binned(c) || want_wide(c) || c->nnz == 0) return 0;
-    const uint64_t nblk = ((uint64_t)c->n + 63) / 64, maxblk = TEAM_R_CAP / 64;
-    uint32_t T = 1;
-    while (T <= (uint32_t)TEAM_MAX && (nblk + T - 1) / T > maxblk) T *= 2;
-    if (c->opt_.team_size > 0) {
-        uint32_t f = 1;
-        while (f < (uint32_t)c->opt_.team_size && f < (uint32_t)TEAM_MAX) f *= 2;
-        T = std::max(T, f);
-    }
-    if (T > (uint32_t)TEAM_MAX || T > (uint32_t)std::max(1, c->prop.multiProcessorCount)) return 0;
-    return T;
+static bool want_team(const fora_ctx *c) {
+    const bool on = c->opt_.team == 1 || (c->opt_.team < 0 && c->dangling_frac > 0.2);
+    return on && want_binned(c) && !want_wide(c) && c->nnz > 0;
 }
 int ensure_team(fora_ctx *c) {
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
-    const uint32_t T = want_team_size(c);
-    if (T == c->team_T && (T == 0 || c->d_colt)) return FORA_OK;
-    dfree(c->d_colt); dfree(c->d_team_off);
-    c->team_T = 0; c->team_R = 0; c->team_cap = 0;
-    if (T == 0) return FORA_OK;
+    const bool want = want_team(c);
+    const uint32_t force = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_size, 0), TEAM_MAX);
+    if (c->team_checked && want == c->team_wanted && (!want || c->team_force == force)) return FORA_OK;
+    c->team_checked = true; c->team_wanted = want;
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16);
+    c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_force = force;
+    if (!want) return FORA_OK;
     const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
-    const uint32_t nblk = (uint32_t)((n + 63) / 64);
-    const uint32_t R = ((nblk + T - 1) / T) * 64;
     std::vector<int32_t> col(nnz);
     HIPCHK(c, hipMemcpy(col.data(), c->d_col, nnz * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> indeg(n, 0);
+    for (size_t e = 0; e < nnz; e++) indeg[(size_t)col[e]]++;
+    // members per team: the fewest (a power of two) whose LDS holds their share of the nodes that have in-edges
+    uint32_t T = 1;
+    while (T < force) T *= 2;
+    std::vector<uint32_t> cntm;
+    uint32_t R = 0;
+    for (;; T *= 2) {
+        if (T > (uint32_t)TEAM_MAX || T > (uint32_t)std::max(1, c->prop.multiProcessorCount)) return FORA_OK; // too large for the team path
+        cntm.assign(T, 0);
+        for (size_t v = 0; v < n; v++) if (indeg[v]) cntm[(v >> 6) % T]++;
+        R = (*std::max_element(cntm.begin(), cntm.end()) + 63) / 64 * 64;
+        if (R == 0) R = 64;
+        if (R <= TEAM_R_CAP) break;
+    }
+    std::vector<uint32_t> n2l(n, TEAM_EMPTY), l2n((size_t)T * R, TEAM_EMPTY);
+    std::vector<uint16_t> deg16((size_t)T * R, 0);
+    std::fill(cntm.begin(), cntm.end(), 0);
+    for (size_t v = 0; v < n; v++) {
+        if (!indeg[v]) continue;
+        const uint32_t s = (uint32_t)((v >> 6) % T), l = cntm[s]++;
+        n2l[v] = (s << TEAM_LBITS) | l;
+        l2n[(size_t)s * R + l] = (uint32_t)v;
+        deg16[(size_t)s * R + l] = (uint16_t)std::min<int64_t>(c->h_row_ptr[v + 1] - c->h_row_ptr[v], 0xFFFF);
+    }
     std::vector<uint32_t> colt(nnz);
     std::vector<uint64_t> pair((size_t)T * T, 0);
     for (size_t v = 0; v < n; v++) {
         const uint32_t s = (uint32_t)((v >> 6) % T);
         for (int64_t e = c->h_row_ptr[v]; e < c->h_row_ptr[v + 1]; e++) {
-            const uint32_t w = (uint32_t)col[(size_t)e], b = w >> 6;
-            const uint32_t dd = b % T, local = ((b / T) << 6) | (w & 63u);
-            colt[(size_t)e] = (dd << TEAM_LBITS) | local;
-            pair[(size_t)s * T + dd]++;
+            const uint32_t w = n2l[(size_t)col[(size_t)e]];
+            colt[(size_t)e] = w;
+            pair[(size_t)s * T + (w >> TEAM_LBITS)]++;
         }
     }
     // bucket (s -> d): one 4-byte message per edge + the dangling mass of the level; whole 64-byte lines
@@ -443,8 +464,14 @@ int ensure_team(fora_ctx *c) {
     off[(size_t)T * T] = (uint32_t)at;
     HIPCHK(c, hipMalloc(&c->d_colt, nnz * 4));
     HIPCHK(c, hipMalloc(&c->d_team_off, off.size() * 4));
+    HIPCHK(c, hipMalloc(&c->d_team_n2l, n * 4));
+    HIPCHK(c, hipMalloc(&c->d_team_l2n, l2n.size() * 4));
+    HIPCHK(c, hipMalloc(&c->d_team_deg16, deg16.size() * 2));
     HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), nnz * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_team_n2l, n2l.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_team_l2n, l2n.data(), l2n.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_team_deg16, deg16.data(), deg16.size() * 2, hipMemcpyHostToDevice));
     c->team_T = T; c->team_R = R; c->team_cap = at;
     return FORA_OK;
 }
@@ -795,7 +822,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
 // Team push of a batch (fora_team.h): ONE launch runs every slot's push down to a small frontier with the residue
 // resident in LDS, k_push_tail finishes the slots.  Nothing here waits for the device.
 static bool use_team(const fora_ctx *c, const Dev &d) {
-    return c->team_T && c->d_team_msg && c->binned && !d.wide && !c->balanced && d.rounds <= 1 && d.defer_k == 0 && c->opt_.team == 1;
+    return c->team_T && c->d_team_msg && c->binned && !d.wide && !c->balanced && d.rounds <= 1 && d.defer_k == 0 && want_team(c);
 }
 int run_push_team(fora_ctx *c, const Dev &d) {
     const uint32_t T = c->team_T, nteams = c->team_n;
@@ -803,13 +830,13 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.n = d.n; a.nq = d.nq; a.rowinfo = d.rowinfo; a.row_ptr = d.row_ptr; a.deg = d.deg; a.src = d.src;
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
-    a.T = T; a.R = c->team_R; a.nteams = nteams; a.nblk = (uint32_t)(((uint64_t)c->n + 63) / 64);
-    a.colt = c->d_colt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
+    a.T = T; a.R = c->team_R; a.nteams = nteams;
+    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 4 * 16 * 2;
     // frontier size of a slot at which k_push_tail (one workgroup per slot, global atomics) takes over; 0: never
-    const int64_t tail_auto = 4096;
+    const int64_t tail_auto = c->dangling_frac > 0.2 ? 0 : 4096; // (dangling graphs: the long cascade of small levels is cheaper inside the team, ws-sized R-MAT 46.8 ms against 51.2)
     a.tail_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_tail < 0 ? tail_auto : c->opt_.team_tail, 0), 0x7FFFFFFF);
     if (c->opt_.tail == 0) a.tail_max = 0; // `tail` 0 keeps k_push_tail out of every path (tests)
     a.tail_always = c->opt_.tail_always == 1 ? 1u : 0u;
@@ -817,9 +844,9 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.xcd = (c->opt_.team_xcd == 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? 1u : 0u;
     a.stamps = c->d_stamps;
     a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
-    const size_t lds = (size_t)a.R * 8;
+    const size_t lds = ((size_t)a.R + 1) * 8;
     if (!c->team_attr) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TEAM_R_CAP * 8)));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TEAM_R_CAP + 1) * 8)));
         c->team_attr = true;
     }
     HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 4 * 16 * 2) * 4, c->stream));
@@ -1114,7 +1141,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap;
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
@@ -1479,8 +1506,10 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->bk_scale = 1;
     std::vector<uint64_t> rowinfo((size_t)n);
     std::vector<uint32_t> deg((size_t)n);
+    int64_t n_dangling = 0;
     for (int32_t v = 0; v < n; v++) {
         const uint64_t dg = (uint64_t)(row_ptr[v + 1] - row_ptr[v]);
+        n_dangling += dg == 0;
         if (dg > 0xFFFFFFFFull) return fail(c, FORA_E_ARG, "out-degree over 2^32");
         deg[v] = (uint32_t)dg;
         rowinfo[v] = ((uint64_t)row_ptr[v] << 24) | std::min<uint64_t>(dg, DEG_SAT);
@@ -1515,6 +1544,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     }
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
+    c->dangling_frac = (double)n_dangling / (double)n;
     if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
     if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
     return FORA_OK;

@@ -4,16 +4,18 @@
 // The bucketed push of fora_kernels.h (k_pushq_bin + k_accum) keeps one level of increments in LDS and sends the
 // residue HBM -> LDS sum -> HBM every level: at the mid-size levels of a ws-sized query that rewrite of the slot's slab
 // is most of the bytes the pair moves.  Here a TEAM of T workgroups, one per CU, owns a slot from its
-// first level to (nearly) its last: member c keeps the residue of the nodes it owns in LDS (64-node blocks dealt
-// round-robin: owner(v) = (v >> 6) % T, R = 64 * ceil(blocks / T) <= 19 072 nodes = 149 KB of u64), and a level is
+// first level to (nearly) its last.  Member c keeps the residue of the nodes it owns in LDS: 64-node blocks are dealt
+// round-robin (owner(v) = (v >> 6) % T) and only nodes that HAVE in-edges get a local id (nothing ever lands on the
+// others; the slot's source, if it is one of them, uses the spare id R).  A level is
 //
 //   consume   the 4-byte messages the T members wrote for me in the previous level: ds_add_u64 into my residue
-//   sweep     my R residue words against their thresholds (algo.h:1012): whoever is at or over it is this level's
-//             frontier -- after a level's pops every residue is under its threshold, so "crossed during the level" and
-//             "is at or over it now" are the same set
+//   sweep     my residue words against their thresholds (algo.h:1012): whoever is at or over it is this level's frontier
+//             -- after a level's pops every residue is under its threshold, so "crossed during the level" and "is at or
+//             over it now" are the same set.  The out-degrees a thread compares with sit in its registers for the whole
+//             launch (16 bits each): the sweep issues no global load
 //   pop+emit  every wave on its own, 64 frontier nodes at a time: residue -> reserve + increment (algo.h:983-1002, one
-//             lane per node), then their out-edges from a copy of col that names every target as (owner, local id): one
-//             message into the exact-capacity bucket (me -> owner), place taken from an LDS counter
+//             lane per node), then their out-edges from a copy of col that names every target as (owner, local id); the
+//             256 messages of a chunk are sorted by owner in a wave-private LDS stage and leave as one run per bucket
 //   barrier   ONE device-scope barrier of the team per level (arrive = atomic add of 2^32 + my pops on a word that
 //             rotates over four; the sum of the pops is the level's frontier size, read by every member)
 //
@@ -26,9 +28,13 @@
 //
 // Message word (4 bytes): local target (15 bits) | entry << 15, where `entry` names the popped node in the producer's
 // increment table of the level (one 8-byte word per pop, written once, coalesced; the consumer gathers it from L2 --
-// a bucket's messages follow the producer's pop order, so neighbouring lanes gather neighbouring entries).  First
-// version: 8-byte messages with the increment inline -- 67 GB written and 67 GB read per 1000 ws queries, and both the
-// consume and the emit phase ran at the memory system's rate.
+// a bucket's messages follow the producer's pop order, so neighbouring lanes gather neighbouring entries).
+//
+// What was measured on the way (ws-sized graph, 1000 queries, push only; bucketed kernels 75 ms): 8-byte messages with
+// the increment inline and block-wide batches of 1024 pops 95 ms (one exposed HBM round trip per batch, 67 GB of messages
+// each way); waves on their own 90; 4-byte messages 82 -- at which point 3.05 G of the kernel's 5.4 G L2 requests were
+// 4-byte message stores (2.8 messages per request) and the L1 sat stalled on pending requests 58 % of its cycles
+// (profiles/r04_pmc_team_v3.txt), hence the sorted stage.
 #pragma once
 #include "fora_kernels.h"
 
@@ -38,14 +44,19 @@ constexpr int TEAM_MAX = 32;                  // members of a team (5 bits of a 
 constexpr int TEAM_LBITS = 15;                // bits of a local id
 constexpr int TEAM_THREADS = 1024;            // one workgroup per CU
 constexpr int TEAM_NW = TEAM_THREADS / 64;
-constexpr uint32_t TEAM_R_CAP = 17792;        // local ids per member at most: 8 * R + the static LDS below <= 160 KiB
+constexpr int TEAM_NIT = 15;                  // sweep iterations at most (ids per thread): R <= 15 * 1024
+constexpr uint32_t TEAM_R_CAP = 15296;        // local ids per member at most: 8 * (R + 1) + the static LDS below <= 160 KiB
 #ifndef FORA_TEAM_EPT
 #define FORA_TEAM_EPT 4
 #endif
 #ifndef FORA_TEAM_CU
 #define FORA_TEAM_CU 4
 #endif
+#ifndef FORA_TEAM_STAGE
+#define FORA_TEAM_STAGE 0 // 1: a chunk's messages leave sorted by destination through a wave-private LDS stage (measured: not faster)
+#endif
 constexpr int TEAM_EPT = FORA_TEAM_EPT;       // consecutive edges a lane gathers per chunk
+constexpr int TEAM_CHUNK = 64 * TEAM_EPT;     // messages of a chunk = entries of a wave's stage
 constexpr uint32_t TEAM_LMASK = (1u << TEAM_LBITS) - 1u;
 constexpr uint32_t TEAM_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t ERR_TEAM_TIMEOUT = 16, ERR_TEAM_CAP = 32;
@@ -65,8 +76,11 @@ struct TeamDev {
     QState *qs;
     uint32_t *err;
     uint64_t afix, t1;
-    uint32_t T, R, nteams, nblk;   // members per team; local ids per member; teams of the launch; 64-node blocks of the graph
+    uint32_t T, R, nteams;         // members per team; local ids per member (a multiple of 64; id R: the slot's source when it has no in-edge); teams of the launch
     const uint32_t *colt;          // [nnz] owner << 15 | local id of every edge target, rows as in col
+    const uint32_t *n2l;           // [n] owner << 15 | local id of a node, TEAM_EMPTY for a node without in-edges
+    const uint32_t *l2n;           // [T][R] node of a local id (TEAM_EMPTY: unused id)
+    const uint16_t *deg16;         // [T][R] its out-degree, saturating at 0xFFFF (then Dev::deg has it)
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
     uint32_t *msg;                 // [nteams][2][off[T * T]]
     uint64_t *inct;                // [nteams][2][T][R + 64] increment tables: entry e of member s = the increment of its e-th pop of the level
@@ -84,9 +98,6 @@ struct TeamDev {
 __device__ __forceinline__ uint32_t team_deg(const TeamDev &a, uint64_t ri, uint32_t v) { // exact out-degree (see ri_deg)
     const uint32_t dg = (uint32_t)ri & DEG_SAT;
     return dg == DEG_SAT ? (uint32_t)(a.row_ptr[v + 1] - (int64_t)(ri >> 24)) : dg;
-}
-__device__ __forceinline__ uint32_t team_node(uint32_t l, uint32_t me, uint32_t T) { // local id -> node
-    return ((((l >> 6) * T + me) << 6) | (l & 63u));
 }
 
 // one poll loop for everything a member waits for: returns false when the launch is being abandoned
@@ -116,31 +127,83 @@ __device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE 
 #define TSTAMP(k) do {} while (0)
 #define TSTAMP_FLUSH() do {} while (0)
 #endif
-// grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * R bytes.
-//
-// Inside a level nothing but the consume -> sweep and the emit -> barrier seams is a workgroup barrier: every WAVE sweeps
-// 64-id groups (drawn from a shared counter), collects the crossing nodes in a wave-private list and pops / emits them 128
-// at a time on its own (prefix sums by wave scan, in a wave-private LDS area), so the sixteen waves of a member overlap each
-// other's memory round trips and every round trip carries two pops or eight edges per lane.  (First version: block-wide batches of 1024 pops between barriers --
-// one exposed HBM round trip per batch, 46 % of the kernel's cycles.)  Rows of more than TEAM_HEAVY edges are parked in a
-// small list and relaxed by the whole workgroup afterwards, consecutive lanes on consecutive edges.
-constexpr uint32_t TEAM_HEAVY = 1024;
+
+constexpr uint32_t TEAM_HEAVY = 1024; // rows of more edges are relaxed by the whole workgroup, consecutive lanes on consecutive edges
 constexpr int TEAM_NHEAVY = 128;
-constexpr int TEAM_WB = 128;          // nodes a wave pops per batch: two per lane, their loads in flight together
-constexpr int TEAM_MAXGROUPS = 304;  // 64-id groups of a member at most (R <= 19 456)
+constexpr int TEAM_MAXGROUPS = 256;   // 64-id groups of a member at most, the spare id's included
+
+// A wave's stage: the messages of a chunk sorted by destination member (counting sort over <= 32 keys: an LDS histogram
+// gives every message its rank, one atomic per (chunk, destination) on the workgroup's fill counters gives the run its
+// place in the bucket), written out with consecutive lanes on consecutive words of a run.
+struct TeamStage {
+    uint32_t msg[TEAM_CHUNK];
+    uint8_t dst[TEAM_CHUNK];
+    uint32_t hist[TEAM_MAX], offs[TEAM_MAX], delta[TEAM_MAX];
+};
+// word[k] / dst[k]: this lane's messages (dst TEAM_EMPTY: none); s_fill, s_moff: the workgroup's per-destination counters / bucket starts
+__device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT],
+                                          uint32_t *s_fill, const uint32_t *s_moff, uint32_t *mout, uint32_t T, int lane) {
+#if !FORA_TEAM_STAGE
+    // direct form: every message takes its place from the workgroup's fill counter and is stored on its own
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++)
+        if (dst[k] != TEAM_EMPTY) mout[s_moff[dst[k]] + atomicAdd(&s_fill[dst[k]], 1u)] = word[k];
+    return;
+#endif
+    if (lane < TEAM_MAX) st.hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank[TEAM_EPT];
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++) {
+        rank[k] = 0;
+        if (dst[k] != TEAM_EMPTY) rank[k] = atomicAdd(&st.hist[dst[k]], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t c = (uint32_t)lane < T ? st.hist[lane] : 0u;
+    uint32_t total;
+    const uint32_t ex = wave_excl_scan(c, total);
+    if ((uint32_t)lane < T) {
+        const uint32_t gp = c ? atomicAdd(&s_fill[lane], c) : 0u;
+        st.offs[lane] = ex;
+        st.delta[lane] = s_moff[lane] + gp - ex; // bucket slot of stage entry i of this destination: delta + i
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++) {
+        if (dst[k] != TEAM_EMPTY) {
+            const uint32_t slot = st.offs[dst[k]] + rank[k];
+            st.msg[slot] = word[k];
+            st.dst[slot] = (uint8_t)dst[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < TEAM_EPT; j++) {
+        const uint32_t i = j * 64 + lane;
+        if (i < total) mout[st.delta[st.dst[i]] + i] = st.msg[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * (R + 1) bytes.
+//
+// Inside a level nothing but the consume -> sweep and the emit -> barrier seams is a workgroup barrier: the waves draw the
+// level's 64-id groups from a shared counter, collect the crossing nodes in a wave-private list and pop / emit them 64 at a
+// time on their own (prefix sums by wave scan), so the sixteen waves of a member overlap each other's memory round trips.
 __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
-    extern __shared__ uint64_t res[];                        // [R] residue of my nodes
-    __shared__ uint32_t w_pref[TEAM_NW][TEAM_WB + 1];        // per wave: exclusive prefix of the out-degrees of the nodes of its batch
-    __shared__ uint32_t w_area[TEAM_NW][TEAM_WB];            // per wave: local ids (u16) of crossing nodes waiting to be popped; over them, once read, the first edge of every node of the batch
+    extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id
+    __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
+    __shared__ uint32_t w_pref[TEAM_NW][65];                 // per wave: exclusive prefix of the out-degrees of the nodes of its batch
+    __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
     __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree
-    __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX], s_mcap[TEAM_MAX]; // messages I have put into bucket (me -> d) this level; its first slot; its size
-    __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 64-message segments; bucket (s -> me)
+    __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
+    __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 128-message segments; bucket (s -> me)
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext;
-    const uint32_t tstride = a.R + 64; // entries of one increment table
     __shared__ unsigned long long s_dang, s_acc[3];
 
     const uint32_t T = a.T, R = a.R;
+    const uint32_t tstride = R + 64; // entries of one increment table
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t team, me;
@@ -152,12 +215,22 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
         team = blockIdx.x / T;
         me = blockIdx.x % T;
     }
-    const uint32_t nit = (R + TEAM_THREADS - 1) / TEAM_THREADS;
+    const uint32_t nit = (R + TEAM_THREADS - 1) / TEAM_THREADS; // <= TEAM_NIT
+    const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
     const uint64_t cap_total = a.off[T * T];
+    const uint32_t *l2n = a.l2n + (uint64_t)me * R;
     unsigned long long *sync = a.sync + (uint64_t)team * 4 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
-    for (uint32_t l = tid; l < R; l += TEAM_THREADS) res[l] = 0;
-    if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_mcap[tid] = a.off[me * T + tid + 1] - a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
+    for (uint32_t l = tid; l <= R; l += TEAM_THREADS) res[l] = 0;
+    if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
+    // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
+    uint32_t dgp[(TEAM_NIT + 1) / 2];
+#pragma unroll
+    for (int it = 0; it < TEAM_NIT; it++) {
+        const uint32_t l = it * TEAM_THREADS + tid;
+        const uint32_t dv = ((uint32_t)it < nit && l < R) ? (uint32_t)a.deg16[(uint64_t)me * R + l] : 0u;
+        if (it & 1) dgp[it >> 1] |= dv << 16; else dgp[it >> 1] = dv;
+    }
     __syncthreads();
     TSTAMP_DECL
     uint32_t g = 0; // barriers this team has passed: message / count buffers by g & 1, barrier words by g & 3
@@ -181,9 +254,12 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
         TSTAMP(7);
         if (q >= (uint32_t)a.nq) break;
         const uint32_t src = (uint32_t)a.src[q];
-        if (a.deg[src] == 0) continue; // dangling source: k_init_batch has written the whole answer (algo.h:961-965)
+        const uint32_t src_deg = a.deg[src];
+        if (src_deg == 0) continue; // dangling source: k_init_batch has written the whole answer (algo.h:961-965)
         const uint64_t slab = (uint64_t)q * a.n;
-        const uint32_t src_owner = (src >> 6) % T, src_local = (((src >> 6) / T) << 6) | (src & 63u);
+        const uint32_t src_owner = (src >> 6) % T;
+        const uint32_t src_word = a.n2l[src];
+        const uint32_t src_local = src_word == TEAM_EMPTY ? R : (src_word & TEAM_LMASK); // no in-edge: the spare id
         uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
         uint32_t peak = 0, nlev = 0;
         bool final_round = false;
@@ -243,49 +319,67 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                 TSTAMP(0);
             }
             // ================= sweep: who is at or over the threshold (algo.h:1012).  Thread t looks at local ids
-            // it * 1024 + t: wave w owns the 64-id groups it * 16 + w.
+            // it * 1024 + t, i.e. wave w at the 64-id groups it * 16 + w; no global load (out-degrees in registers).
             uint32_t crossmask = 0;
             if (tid < TEAM_MAX) s_fill[tid] = 0;
             if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; }
             if (L > 0) {
-                constexpr int SG = 6; // iterations whose loads are in flight together
-                for (uint32_t g0 = 0; g0 < nit; g0 += SG) {
-                    uint64_t r[SG];
-                    uint32_t dg[SG];
+                constexpr int SG = 5; // LDS reads in flight together (TEAM_NIT = 3 * SG)
 #pragma unroll
-                    for (int k = 0; k < SG; k++) {
-                        const uint32_t l = (g0 + k) * TEAM_THREADS + tid;
-                        r[k] = ((uint32_t)(g0 + k) < nit && l < R) ? res[l] : 0ull;
-                    }
+                for (int g0 = 0; g0 < TEAM_NIT; g0 += SG) {
+                    if ((uint32_t)g0 < nit) { // wave-uniform
+                        uint64_t r[SG];
 #pragma unroll
-                    for (int k = 0; k < SG; k++) {
-                        dg[k] = 1;
-                        if (r[k]) dg[k] = a.deg[team_node((g0 + k) * TEAM_THREADS + tid, me, T)];
-                    }
+                        for (int k = 0; k < SG; k++) {
+                            const uint32_t l = (g0 + k) * TEAM_THREADS + tid;
+                            r[k] = ((uint32_t)(g0 + k) < nit && l < R) ? res[l] : 0ull;
+                        }
 #pragma unroll
-                    for (int k = 0; k < SG; k++) {
-                        const bool c = r[k] && r[k] >= node_thr(a.t1, dg[k]);
-                        if (c) crossmask |= 1u << (g0 + k);
-                        if (g0 + k < nit) { // wave-uniform; group (it, wave) = local ids (it * 16 + wave) * 64 ...
-                            const unsigned long long mk = __ballot(c);
-                            if (lane == 0) s_gmask[(g0 + k) * TEAM_NW + wid] = mk;
+                        for (int k = 0; k < SG; k++) {
+                            const int it = g0 + k;
+                            if ((uint32_t)it < nit) { // wave-uniform
+                                bool c = false;
+                                if (r[k]) {
+                                    uint32_t dg = (dgp[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu;
+                                    if (dg == 0xFFFFu) dg = a.deg[l2n[it * TEAM_THREADS + tid]]; // a hub: its exact degree
+                                    c = r[k] >= node_thr(a.t1, dg);
+                                }
+                                if (c) crossmask |= 1u << it;
+                                const unsigned long long mk = __ballot(c);
+                                const uint32_t gi = it * TEAM_NW + wid;
+                                if (lane == 0 && gi < ngroups - 1) s_gmask[gi] = mk;
+                            }
                         }
                     }
                 }
-            } else if (me == src_owner && wid == 0) { // the source is popped whatever its threshold (algo.h:969-978)
-                if (lane == 0) res[src_local] = FIX_ONE;
+                if (tid == 0) { // the spare id (the source, if it has no in-edge: only dangling mass ever lands there)
+                    const uint64_t rs = res[R];
+                    s_gmask[ngroups - 1] = (me == src_owner && rs && rs >= node_thr(a.t1, src_deg)) ? 1ull : 0ull;
+                }
+            } else if (me == src_owner && tid == 0) { // the source is popped whatever its threshold (algo.h:969-978)
+                res[src_local] = FIX_ONE;
             }
             TSTAMP(1);
-            __syncthreads(); // s_fill / s_dang / counters are zeroed; (level 0) the source's residue is in place
+            __syncthreads(); // s_fill / s_dang / counters are zeroed, the masks are in place; (level 0) so is the source's residue
             if (final_round) {
                 // ================= hand-over: crossing nodes -> (node, residue taken) entries of the slot's frontier list
                 // (k_push_tail pops them, see k_accum), then my residue range -> the slot's slab
                 uint32_t mine = 0;
                 for (uint32_t it = 0; it < nit; it++) mine += (uint32_t)__popcll(__ballot((crossmask >> it) & 1u));
+                const bool spare = wid == 0 && s_gmask[ngroups - 1] != 0; // (wave-uniform)
+                if (spare) mine++;
                 if (mine) { // wave-uniform
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&a.fl_count0[q * CSTRIDE], mine);
                     base = __shfl(base, 0);
+                    if (spare) {
+                        if (lane == 0) {
+                            if (base < (uint32_t)a.n) { a.fl0[slab + base] = src; a.inc_tab0[(uint64_t)q * a.segq_cap + base] = res[R]; }
+                            else atomicOr(a.err, ERR_WL_OVERFLOW);
+                            res[R] = 0;
+                        }
+                        base++;
+                    }
                     for (uint32_t it = 0; it < nit; it++) {
                         const bool c = (crossmask >> it) & 1u;
                         const unsigned long long mk = __ballot(c);
@@ -293,7 +387,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                             const uint32_t l = it * TEAM_THREADS + tid;
                             const uint32_t pos = base + (uint32_t)__popcll(mk & lt_mask);
                             if (pos < (uint32_t)a.n) {
-                                a.fl0[slab + pos] = team_node(l, me, T);
+                                a.fl0[slab + pos] = l2n[l];
                                 a.inc_tab0[(uint64_t)q * a.segq_cap + pos] = res[l];
                             } else atomicOr(a.err, ERR_WL_OVERFLOW);
                             res[l] = 0;
@@ -302,131 +396,119 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                     }
                 }
                 for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
-                    const uint32_t v = team_node(l, me, T);
-                    if (v < (uint32_t)a.n) a.residue[slab + v] = res[l];
+                    const uint32_t v = l2n[l];
+                    if (v != TEAM_EMPTY) a.residue[slab + v] = res[l];
                     res[l] = 0;
+                }
+                if (tid == 0) { // (the same thread that may have handed the spare id over)
+                    if (me == src_owner && src_word == TEAM_EMPTY) a.residue[slab + src] = res[R];
+                    res[R] = 0;
                 }
                 TSTAMP(6);
                 break;
             }
-            // ================= pop + emit, every wave on its own.  The waves draw the level's 64-id groups from a shared
-            // counter (a group whose nodes have long rows keeps one wave busy while the others take the rest), collect the
-            // crossing nodes in a wave-private list and pop TEAM_WB of them at a time, two per lane.
+            // ================= pop + emit, every wave on its own.  The waves draw the level's 64-id groups four at a time
+            // from a shared counter (a group whose nodes have long rows keeps one wave busy while the others take the
+            // rest), collect the crossing nodes in a wave-private list and pop 64 of them at a time.
             uint32_t *mout = a.msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
             uint64_t *tout = a.inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride; // my increment table of this level
             uint64_t my_dang = 0;
             {
-                uint16_t *list = (uint16_t *)w_area[wid]; // [2 * TEAM_WB] entries fit the area; TEAM_WB + 63 are used at most
-                uint32_t *ebegs = w_area[wid];
+                uint16_t *list = w_list[wid];
                 uint32_t *pref = w_pref[wid];
-                const uint32_t ngroups = L == 0 ? 0u : nit * TEAM_NW;
-                uint32_t npend = 0;
+                TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
+                uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
                 if (L == 0) { drained = true; if (me == src_owner && wid == 0) { if (lane == 0) list[0] = (uint16_t)src_local; npend = 1; } }
                 for (;;) {
-                    while (!drained && npend < (uint32_t)TEAM_WB) { // draw groups until a batch is full
-                        uint32_t gi = 0;
-                        if (lane == 0) gi = atomicAdd(&s_gnext, 1u);
-                        gi = (uint32_t)__shfl((int)gi, 0);
-                        if (gi >= ngroups) { drained = true; break; }
+                    while (npend < 64) { // look at groups until a batch is full (the list holds 128)
+                        if (gcur == gend) {
+                            if (drained) break;
+                            uint32_t g4 = 0;
+                            if (lane == 0) g4 = atomicAdd(&s_gnext, 4u);
+                            g4 = (uint32_t)__shfl((int)g4, 0);
+                            if (g4 >= ngroups) { drained = true; break; }
+                            gcur = g4; gend = min(g4 + 4u, ngroups);
+                        }
+                        const uint32_t gi = gcur++;
                         const unsigned long long mk = s_gmask[gi];
-                        if (!mk) continue;
                         if ((mk >> lane) & 1ull) list[npend + (uint32_t)__popcll(mk & lt_mask)] = (uint16_t)(gi * 64 + lane);
                         npend += (uint32_t)__popcll(mk);
                     }
                     if (npend == 0) break;
-                    // ---- pop up to TEAM_WB nodes, two per lane: entries lane and 64 + lane (algo.h:983-1002)
-                    const uint32_t m = min(npend, (uint32_t)TEAM_WB);
-                    const uint32_t left = npend - m; // < 64: they wait in a register while the area holds the batch's row starts
-                    const uint32_t l0 = list[lane], l1 = list[64 + lane];
-                    const uint16_t keep = list[TEAM_WB + (lane < 63 ? lane : 63)];
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                    uint32_t ebase = 0; // my entries of the level's increment table: ebase + entry
+                    // ---- pop up to 64 nodes, one per lane (algo.h:983-1002)
+                    const uint32_t m = min(npend, 64u);
+                    uint32_t cnt = 0, ebeg = 0;
+                    uint32_t ebase = 0; // my entries of the level's increment table: ebase + lane
                     if (lane == 0) ebase = atomicAdd(&s_ncross, m);
                     ebase = (uint32_t)__shfl((int)ebase, 0);
-                    const bool v0ok = (uint32_t)lane < m, v1ok = (uint32_t)lane + 64 < m;
-                    const uint32_t v0 = team_node(l0, me, T), v1 = team_node(l1, me, T);
-                    uint64_t ri0 = 0, ri1 = 0, po0 = 0, po1 = 0;
-                    if (v0ok) { ri0 = a.rowinfo[v0]; po0 = a.ppr[slab + v0]; }
-                    if (v1ok) { ri1 = a.rowinfo[v1]; po1 = a.ppr[slab + v1]; }
-                    uint32_t cnt0 = 0, cnt1 = 0;
-                    if (v0ok) {
-                        const uint64_t rr = res[l0];
-                        res[l0] = 0;                                         // algo.h:984-985
-                        const uint32_t deg = team_deg(a, ri0, v0);
+                    if ((uint32_t)lane < m) {
+                        const uint32_t l = list[lane];
+                        const uint32_t v = l == R ? src : l2n[l];
+                        const uint64_t ri = a.rowinfo[v];
+                        const uint64_t rsv_old = a.ppr[slab + v];
+                        const uint64_t rr = res[l];
+                        res[l] = 0;                                       // algo.h:984-985
+                        const uint32_t deg = team_deg(a, ri, v);
                         uint64_t rsv_add, dang;
                         const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                        if (rsv_add) a.ppr[slab + v0] = po0 + rsv_add;       // algo.h:986-989 (this member owns v0)
+                        if (rsv_add) a.ppr[slab + v] = rsv_old + rsv_add; // algo.h:986-989 (this member owns v)
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
-                        cnt0 = inc ? deg : 0u;
-                        if (cnt0) tout[ebase + lane] = inc;
-                        if (cnt0 > TEAM_HEAVY) { // a hub's row: relaxed by the whole workgroup after the waves' own rows
+                        ebeg = (uint32_t)(ri >> 24);
+                        cnt = inc ? deg : 0u;
+                        if (cnt) tout[ebase + lane] = inc;
+                        if (cnt > TEAM_HEAVY) { // a hub's row: relaxed by the whole workgroup after the waves' own rows
                             const uint32_t hi = atomicAdd(&s_nheavy, 1u);
-                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + lane; h_ebeg[hi] = (uint32_t)(ri0 >> 24); h_deg[hi] = cnt0; cnt0 = 0; }
+                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + lane; h_ebeg[hi] = ebeg; h_deg[hi] = cnt; cnt = 0; }
                         }
                     }
-                    if (v1ok) {
-                        const uint64_t rr = res[l1];
-                        res[l1] = 0;
-                        const uint32_t deg = team_deg(a, ri1, v1);
-                        uint64_t rsv_add, dang;
-                        const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                        if (rsv_add) a.ppr[slab + v1] = po1 + rsv_add;
-                        acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
-                        cnt1 = inc ? deg : 0u;
-                        if (cnt1) tout[ebase + 64 + lane] = inc;
-                        if (cnt1 > TEAM_HEAVY) {
-                            const uint32_t hi = atomicAdd(&s_nheavy, 1u);
-                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + 64 + lane; h_ebeg[hi] = (uint32_t)(ri1 >> 24); h_deg[hi] = cnt1; cnt1 = 0; }
-                        }
+                    if (npend > 64) { // keep the entries behind the first 64
+                        const uint16_t keep = list[64 + (lane < 63 ? lane : 63)];
+                        __builtin_amdgcn_wave_barrier();
+                        if ((uint32_t)lane < npend - 64) list[lane] = keep;
                     }
-                    uint32_t tot0, tot1;
-                    const uint32_t pre0 = wave_excl_scan(cnt0, tot0);
-                    const uint32_t pre1 = tot0 + wave_excl_scan(cnt1, tot1);
-                    const uint32_t total = tot0 + tot1;
-                    pref[lane] = pre0; pref[64 + lane] = pre1;
-                    if (lane == 0) pref[TEAM_WB] = total;
-                    ebegs[lane] = (uint32_t)(ri0 >> 24); ebegs[64 + lane] = (uint32_t)(ri1 >> 24);
+                    npend -= m;
+                    uint32_t total;
+                    const uint32_t pre = wave_excl_scan(cnt, total);
+                    pref[lane] = pre;
+                    if (lane == 0) pref[64] = total;
                     TSTAMP(2);
                     // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows
-                    for (uint32_t cb = 0; cb < total; cb += 64 * TEAM_EPT) {
+                    for (uint32_t cb = 0; cb < total; cb += TEAM_CHUNK) {
                         const uint32_t e0 = cb + lane * TEAM_EPT;
                         uint32_t lo = 0;
                         if (e0 < total) {
-                            uint32_t hi = TEAM_WB;
+                            uint32_t hi = 64;
 #pragma unroll
-                            for (int s7 = 0; s7 < 7; s7++) {
+                            for (int s6 = 0; s6 < 6; s6++) {
                                 const uint32_t mid = (lo + hi) >> 1;
                                 if (pref[mid] <= e0) lo = mid; else hi = mid;
                             }
                         }
-                        uint32_t w[TEAM_EPT], si[TEAM_EPT];
-                        uint32_t cur = TEAM_EMPTY, eb = 0, pb = 0;
+                        uint32_t si[TEAM_EPT];
 #pragma unroll
                         for (int k = 0; k < TEAM_EPT; k++) {
                             const uint32_t e = e0 + k;
-                            w[k] = TEAM_EMPTY;
-                            if (e < total) {
-                                while (pref[lo + 1] <= e) lo++; // entries without edges
-                                if (lo != cur) { cur = lo; eb = ebegs[lo]; pb = pref[lo]; }
-                                w[k] = a.colt[(uint64_t)eb + (e - pb)];
-                            }
+                            if (e < total) while (pref[lo + 1] <= e) lo++; // entries without edges
                             si[k] = lo;
                         }
+                        uint32_t w[TEAM_EPT];
+#pragma unroll
+                        for (int k = 0; k < TEAM_EPT; k++) { // (every lane takes part in the exchanges)
+                            const uint32_t e = e0 + k;
+                            const uint32_t eb = (uint32_t)__shfl((int)ebeg, (int)si[k]);
+                            const uint32_t pb = (uint32_t)__shfl((int)pre, (int)si[k]);
+                            w[k] = TEAM_EMPTY;
+                            if (e < total) w[k] = a.colt[(uint64_t)eb + (e - pb)];
+                        }
+                        uint32_t word[TEAM_EPT], dst[TEAM_EPT];
 #pragma unroll
                         for (int k = 0; k < TEAM_EPT; k++) {
-                            if (w[k] == TEAM_EMPTY) continue;
-                            const uint32_t dst = w[k] >> TEAM_LBITS;
-                            const uint32_t pos = atomicAdd(&s_fill[dst], 1u);
-                            if (pos >= s_mcap[dst]) { atomicOr(a.err, ERR_TEAM_CAP); continue; } // cannot happen: the capacity is the bucket's edge count
-                            mout[(uint64_t)s_moff[dst] + pos] = (w[k] & TEAM_LMASK) | ((ebase + si[k]) << TEAM_LBITS);
+                            dst[k] = w[k] == TEAM_EMPTY ? TEAM_EMPTY : w[k] >> TEAM_LBITS;
+                            word[k] = (w[k] & TEAM_LMASK) | ((ebase + si[k]) << TEAM_LBITS);
                         }
+                        team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                    if ((uint32_t)lane < left) list[lane] = keep; // the waiting entries move to the front
-                    npend = left;
                     TSTAMP(3);
                 }
             }
@@ -435,16 +517,24 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             my_dang = wave_sum(my_dang);
             if (lane == 0 && my_dang) atomicAdd(&s_dang, (unsigned long long)my_dang);
             __syncthreads();
-            { // heavy rows: consecutive lanes on consecutive edges
+            { // heavy rows: consecutive lanes on consecutive edges, a chunk per wave and trip
                 const uint32_t nh = min(s_nheavy, (uint32_t)TEAM_NHEAVY);
+                TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
                 for (uint32_t h = 0; h < nh; h++) {
                     const uint32_t eb = h_ebeg[h], dgh = h_deg[h], ent = h_ent[h] << TEAM_LBITS;
-                    for (uint32_t e = tid; e < dgh; e += TEAM_THREADS) {
-                        const uint32_t w = a.colt[(uint64_t)eb + e];
-                        const uint32_t dst = w >> TEAM_LBITS;
-                        const uint32_t pos = atomicAdd(&s_fill[dst], 1u);
-                        if (pos >= s_mcap[dst]) { atomicOr(a.err, ERR_TEAM_CAP); continue; }
-                        mout[(uint64_t)s_moff[dst] + pos] = (w & TEAM_LMASK) | ent;
+                    for (uint32_t c0 = wid * TEAM_CHUNK; c0 < dgh; c0 += TEAM_NW * TEAM_CHUNK) {
+                        uint32_t word[TEAM_EPT], dst[TEAM_EPT];
+#pragma unroll
+                        for (int k = 0; k < TEAM_EPT; k++) {
+                            const uint32_t e = c0 + k * 64 + lane;
+                            dst[k] = TEAM_EMPTY; word[k] = 0;
+                            if (e < dgh) {
+                                const uint32_t w = a.colt[(uint64_t)eb + e];
+                                dst[k] = w >> TEAM_LBITS;
+                                word[k] = (w & TEAM_LMASK) | ent;
+                            }
+                        }
+                        team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
                     }
                 }
             }
@@ -454,15 +544,13 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             if (tid == 0 && s_dang) { // one more table entry, one more message
                 const uint32_t ent = s_ncross, pos = s_fill[src_owner];
                 tout[ent] = s_dang;
-                if (pos >= s_mcap[src_owner]) atomicOr(a.err, ERR_TEAM_CAP);
-                else mout[(uint64_t)s_moff[src_owner] + pos] = src_local | (ent << TEAM_LBITS);
+                mout[s_moff[src_owner] + pos] = src_local | (ent << TEAM_LBITS);
                 s_fill[src_owner] = pos + 1;
             }
             __syncthreads();
             if ((uint32_t)tid < T) (a.cnt + ((uint64_t)team * 2 + (g & 1u)) * T * T)[me * T + tid] = s_fill[tid];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            TSTAMP(4);
             // ================= the team's barrier; the level's frontier size comes with it
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

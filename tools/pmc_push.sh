@@ -13,4 +13,4 @@ for P in "$P1" "$P2" "$P3" "$P4" "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $P -d "$OUT/p$i" -o p --output-format csv -- python3 "$R/tools/pushbench.py" --child --reps 1 "$@" > "$OUT/p$i.log" 2>&1
 done
 python3 "$R/tools/pmc_generic.py" $(find "$OUT" -name '*counter_collection.csv') > "$OUT/summary.txt" 2>&1
-grep -A40 -E "k_pushq_bin|k_accum<false>" "$OUT/summary.txt" | head -120
+grep -A40 -E "k_pushq_bin|k_accum<false>|k_push_team|k_push_tail" "$OUT/summary.txt" | head -120

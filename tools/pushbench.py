@@ -16,7 +16,7 @@ def child(args):
     import numpy as np
     import fora_amd
     from fora_amd import synth
-    n, m, row_ptr, col = synth.preset(args.graph)
+    n, m, row_ptr, col = synth.preset(args.graph, args.dangling)
     eng = fora_amd.Engine(0)
     eng.set_graph(n, m, row_ptr, col)
     eng.set_params(alpha=0.2, epsilon=0.5, seed=0x464F5241)
@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--mode", default="push", choices=["push", "query", "idx"])
+    ap.add_argument("--dangling", default="none", choices=["none", "rmat"])
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -70,7 +71,7 @@ def main():
     for lib in libs:
         env = dict(os.environ, FORA_HIP_LIB=os.path.abspath(lib))
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--graph", args.graph, "--queries", str(args.queries),
-               "--reps", str(args.reps), "--batch", str(args.batch), "--mode", args.mode]
+               "--reps", str(args.reps), "--batch", str(args.batch), "--mode", args.mode, "--dangling", args.dangling]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
         sys.stdout.write(r.stdout)
         if r.returncode:
