@@ -1718,12 +1718,34 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
 // whose residue is at/over this round's threshold.  Bucketed push: a frontier entry is (node, residue taken from it),
 // see k_accum.  grid = (chunks, nq).
 __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *active) {
+    // bucketed push: the workgroup collects its entries in LDS and takes list space with one atomic per ~1000 of them --
+    // one per wave was tens of thousands of returning atomics per slot and round on ONE address (~20 M/s)
+    constexpr uint32_t FB = 2048;
+    __shared__ uint32_t s_node[FB];
+    __shared__ uint64_t s_val[FB];
+    __shared__ uint32_t s_cnt, s_gb;
     const int q = blockIdx.y;
     if (!active[q]) return;
     const int lane = threadIdx.x & 63;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t nchunk = ((uint32_t)d.n + BLOCK - 1) / BLOCK;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    auto flush = [&]() { // all threads; s_cnt entries -> the slot's frontier list
+        const uint32_t cnt = s_cnt;
+        if (threadIdx.x == 0 && cnt) s_gb = atomicAdd(&d.fl_count[0][q * CSTRIDE], cnt);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) {
+            const uint32_t pos = s_gb + i;
+            if (pos < (uint32_t)d.n) { d.fl[0][slab + pos] = s_node[i]; d.inc_tab[0][(uint64_t)q * d.segq_cap + pos] = s_val[i]; }
+            else atomicOr(d.err, ERR_WL_OVERFLOW);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+    };
     for (uint32_t c0 = blockIdx.x * SLAB_UNROLL; c0 < nchunk; c0 += gridDim.x * SLAB_UNROLL) { // see k_walk_alloc
+        if (d.binned && s_cnt > FB - SLAB_UNROLL * BLOCK) flush(); // (uniform: s_cnt is stable between the barriers)
         uint64_t rr[SLAB_UNROLL];
 #pragma unroll
         for (int u = 0; u < SLAB_UNROLL; u++) {
@@ -1743,16 +1765,17 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
             const unsigned long long mask = __ballot(in);
             if (!mask) continue;
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&d.fl_count[0][q * CSTRIDE], (uint32_t)__popcll(mask));
+            if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(mask));
             base = __shfl(base, 0);
             if (in) {
                 d.residue[slab + v] = 0; // algo.h:984-985; k_pushq_bin finishes the pop
                 const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-                if (pos < (uint32_t)d.n) { d.fl[0][slab + pos] = v; d.inc_tab[0][(uint64_t)q * d.segq_cap + pos] = r; }
-                else atomicOr(d.err, ERR_WL_OVERFLOW);
+                s_node[pos] = v; s_val[pos] = r;
             }
         }
+        __syncthreads();
     }
+    if (d.binned) flush();
 }
 
 // ppr := reserve for active slots (compute_ppr_with_reserve, query.h:243-253)
@@ -1782,7 +1805,7 @@ __global__ void __launch_bounds__(BLOCK) k_count_above(Dev d, const uint8_t *act
     for (uint64_t v0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v0 < (uint64_t)d.n; v0 += step * SLAB_UNROLL) {
         uint64_t x[SLAB_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = v0 + u * step < (uint64_t)d.n ? d.ppr[slab + v0 + u * step] : 0;
+        for (int u = 0; u < SLAB_UNROLL; u++) x[u] = (v0 + u * step < (uint64_t)d.n) ? d.ppr[slab + v0 + u * step] : 0;
 #pragma unroll
         for (int u = 0; u < SLAB_UNROLL; u++) acc += x[u] && fix2d(x[u]) >= T; // T > 0
     }
