@@ -125,26 +125,13 @@ def cpu_baseline(g, sources, rmax, omega, args, index):
 
 
 def cpu_all_cores(g, sources, rmax, omega, args, index, threads):
-    """the same oracle on T host threads, sources sharded, private state per call
-    (ctypes releases the GIL around the C call)."""
+    """the same oracle on T host threads, sources t, t + T, ... per thread -- pthreads inside the
+    oracle (orc_query_many), every thread with its own buffers for the whole run.  (Round 3 drove per-call-allocating
+    ctypes calls from a Python thread pool: 10x one thread on 256 threads.)"""
     import oracle_lib as O
-    from concurrent.futures import ThreadPoolExecutor
-    t0 = time.perf_counter()
-    budget = args.cpu_seconds
-
-    def work(tid):
-        done = 0
-        for s in sources[tid::threads]:
-            O.query(g, int(s), rmax, omega, opt=args.opt, seed=0x464F5241, index=index)
-            done += 1
-            if time.perf_counter() - t0 > budget:
-                break
-        return done
-    with ThreadPoolExecutor(threads) as ex:
-        done = sum(ex.map(work, range(threads)))
-    dt = time.perf_counter() - t0
+    done, dt, _ = O.query_many(g, sources, rmax, omega, threads, args.cpu_seconds, opt=args.opt, seed=0x464F5241, index=index)
     return {"value": done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{done} of the bench sources over {threads} threads (sources tid mod T), {dt:.1f} s"}
+            "sample": f"{done} of the bench sources over {threads} pthreads (sources tid mod T, private buffers), {dt:.1f} s"}
 
 
 def accuracy(eng, g, sources, n, m, args, np):
@@ -213,10 +200,14 @@ def plumbing_only(args):
              "per_rank_queries_per_s": {"min": min_over_ranks(my_qps, world if use_dist else 1),
                                         "max": max_over_ranks(my_qps, world if use_dist else 1)}}
     ok = bool((g_ids[:, 0] == all_sources).all())
+    per_rank = {"min": int(min_over_ranks(len(mine), world if use_dist else 1)), "max": int(max_over_ranks(len(mine), world if use_dist else 1))}  # (collectives: every rank)
     if rank == 0:
         print(json.dumps({"metric": "plumbing-only", "value": tot[0] * args.steps / dt, "unit": "queries/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                           "higher_is_better": True, "scaling": args.scaling, "queries_total_per_step": int(tot[0]),
+                          "queries_per_rank": per_rank,
+                          # what the all-gather moves per step: every rank's padded [ceil(Q / G), k] (int32 id, f64 score) lists
+                          "gather_bytes_per_step": int(world * ((len(all_sources) + world - 1) // world) * k * 12),
                           "gather_in_global_order": ok, "ranks": ranks}))
     if use_dist:
         dist.barrier()

@@ -74,9 +74,15 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
+// knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
+// variable must not change what a query returns; fora_hip_set_option sets them (tests, experiments)
+static bool schedule_option(const char *name) {
+    return !strcmp(name, "rounds") || !strcmp(name, "round_div") || !strcmp(name, "defer") || !strcmp(name, "defer_min");
+}
 static Tunables tunables_from_env() {
     Tunables t;
     for (const auto &o : OPTIONS) {
+        if (schedule_option(o.name)) continue;
         std::string env = "FORA_HIP_";
         for (const char *p = o.name; *p; p++) env += (char)toupper((unsigned char)*p);
         if (const char *e = getenv(env.c_str())) if (*e) t.*(o.field) = atoll(e);

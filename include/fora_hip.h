@@ -134,15 +134,14 @@ int fora_hip_set_balanced(fora_ctx *ctx, int on, double start_scale, double c_po
 /* queries processed concurrently per launch; 0 = choose from free HBM */
 int fora_hip_set_batch(fora_ctx *ctx, int batch);
 int fora_hip_get_batch(fora_ctx *ctx);
-/* Engine knobs (layout choice, launch shapes, capacities; the list is `OPTIONS` in fora_hip.hip).  Every knob is read
+/* Engine knobs (layout choice, launch shapes, capacities; the list is `OPTIONS` in fora_hip.hip).  A knob is read
  * once, in fora_hip_create, from the environment variable FORA_HIP_<NAME>; this call changes one afterwards (tests
- * use it to force the wide layout, tiny buckets, the k_push_tail path ...).  Layout, capacity and launch-shape knobs
- * change no result bit.  Three knobs choose another push SCHEDULE and with it other (equally valid) residue / reserve
- * / ppr bits: "rounds" and "round_div" (threshold rounds) and "defer" (bounded deferral); all are off by default, and a
- * run with them equals oracle/fora_twin.c run with the same values (orc_twin_set_rounds / _round_div / _defer).  A stray
- * FORA_HIP_ROUNDS / FORA_HIP_DEFER in the environment therefore changes results: fora_query_stats.levels and .relax
- * show it, and set_option("reset") followed by explicit values rules it out.
- * name "reset": back to the values fora_hip_create read.  Unknown name: FORA_E_ARG. */
+ * use it to force the wide layout, tiny buckets, the k_push_tail or k_push_team path ...).  None of the knobs the
+ * environment can set changes a result bit.  Four knobs choose another push SCHEDULE and with it other (equally valid)
+ * residue / reserve / ppr bits: "rounds", "round_div" (threshold rounds), "defer" and "defer_min" (bounded deferral).
+ * They are off by default, are NOT read from the environment -- only this call sets them -- and a run with them equals
+ * oracle/fora_twin.c run with the same values (orc_twin_set_rounds / _round_div / _defer / _defer_min).
+ * name "reset": back to the defaults / the environment values fora_hip_create read.  Unknown name: FORA_E_ARG. */
 int fora_hip_set_option(fora_ctx *ctx, const char *name, int64_t value);
 
 /* ---- walk index: replaces build() (build.h:302-366), rw_idx / rw_idx_info

@@ -12,7 +12,9 @@
 #include "fora_oracle.h"
 #include <math.h>
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------ loaders */
@@ -177,12 +179,28 @@ int32_t orc_walk(int32_t n, const int64_t *row_ptr, const int32_t *col, uint64_t
 
 /* ------------------------------------------------------------ FIFO push f64 */
 /* algo.h:954-1018 forward_local_update_linear. */
+/* scratch of one push: `idx` (n bytes) is all zero between calls (every node that enters the queue leaves it), `q` grows */
+typedef struct { unsigned char *idx; int32_t *q; int64_t cap; } push_ws;
+static int push_fifo_ws(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
+                        double alpha, double *reserve, double *residue, int32_t *reserve_occur,
+                        int32_t *residue_occur, orc_push_stats *st, push_ws *ws);
 int orc_push_fifo(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
                   double alpha, double *reserve, double *residue, int32_t *reserve_occur,
                   int32_t *residue_occur, orc_push_stats *st) {
+    push_ws ws;
+    ws.idx = (unsigned char *)calloc((size_t)n, 1); /* :958-959 */
+    ws.cap = (int64_t)n + 16;
+    ws.q = (int32_t *)malloc(sizeof(int32_t) * (size_t)ws.cap);
+    const int rc = push_fifo_ws(n, row_ptr, col, s, rmax, alpha, reserve, residue, reserve_occur, residue_occur, st, &ws);
+    free(ws.idx); free(ws.q);
+    return rc;
+}
+static int push_fifo_ws(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
+                        double alpha, double *reserve, double *residue, int32_t *reserve_occur,
+                        int32_t *residue_occur, orc_push_stats *st, push_ws *ws) {
     const double nil = -1.0; /* query.h:1464-1465 */
     for (int32_t i = 0; i < n; i++) { reserve[i] = nil; residue[i] = nil; } /* :955-956 clean() */
-    unsigned char *idx = (unsigned char *)calloc((size_t)n, 1);              /* :958-959 */
+    unsigned char *idx = ws->idx;                                            /* :958-959 */
     int64_t n_res = 0, n_rsd = 0, pops = 0, relax = 0, gens = 0;
     double rsum = 1.0; /* query.h:843 */
 
@@ -194,8 +212,8 @@ int orc_push_fifo(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t
     }
     {
         const double myeps = rmax;
-        int64_t cap = (int64_t)n + 16, qn = 0, left = 0;
-        int32_t *q = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+        int64_t cap = ws->cap, qn = 0, left = 0;
+        int32_t *q = ws->q;
         q[qn++] = s;                               /* :969-973 (sentinel slot omitted) */
         residue[s] = 1.0; residue_occur[n_rsd++] = s; /* :976 insert(s, init_residual) */
         idx[s] = 1;
@@ -243,10 +261,9 @@ int orc_push_fifo(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t
             }
         }
         gens++;
-        free(q);
+        ws->q = q; ws->cap = cap;
     }
 done:
-    free(idx);
     if (st) {
         st->rsum = rsum; st->pops = pops; st->relax = relax;
         st->n_reserve = n_res; st->n_residue = n_rsd; st->generations = gens;
@@ -368,6 +385,75 @@ int orc_query(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, 
     if (pst) *pst = ps;
     free(reserve); free(residue); free(o1); free(o2);
     return 0;
+}
+
+/* The query() loop of query.h:1471-1476 over T host threads for bench.py's all-core baseline: thread t takes sources
+ * t, t + T, ... until `seconds` have passed; every thread owns its buffers for the whole run (per-call malloc / free of
+ * n-sized arrays is an mmap / munmap pair each, which serialised 256 Python threads on the kernel's address-space lock:
+ * 10x one thread).  Returns the queries finished; *elapsed = wall time of the slowest thread. */
+typedef struct {
+    int32_t n; const int64_t *row_ptr; const int32_t *col; const int32_t *sources; int64_t nsrc;
+    double rmax, omega, alpha; int opt; uint64_t seed;
+    const int32_t *rw_idx; const uint64_t *off, *cnt;
+    int tid, threads; double seconds;
+    int64_t done; uint64_t walks; double elapsed;
+} many_arg;
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *many_worker(void *p) {
+    many_arg *a = (many_arg *)p;
+    const size_t n = (size_t)a->n;
+    double *reserve = (double *)malloc(sizeof(double) * n), *residue = (double *)malloc(sizeof(double) * n);
+    double *ppr = (double *)malloc(sizeof(double) * n);
+    int32_t *o1 = (int32_t *)malloc(sizeof(int32_t) * n), *o2 = (int32_t *)malloc(sizeof(int32_t) * n);
+    push_ws ws;
+    ws.idx = (unsigned char *)calloc(n, 1);
+    ws.cap = (int64_t)n + 16;
+    ws.q = (int32_t *)malloc(sizeof(int32_t) * (size_t)ws.cap);
+    const double t0 = now_s();
+    for (int64_t i = a->tid; i < a->nsrc; i += a->threads) {
+        orc_push_stats ps;
+        orc_refine_stats rs;
+        push_fifo_ws(a->n, a->row_ptr, a->col, a->sources[i], a->rmax, a->alpha, reserve, residue, o1, o2, &ps, &ws);
+        orc_refine(a->n, a->row_ptr, a->col, a->sources[i], reserve, o1, ps.n_reserve, residue, o2, ps.n_residue, ps.rsum,
+                   a->omega, a->alpha, a->opt, a->seed, a->rw_idx, a->off, a->cnt, ppr, &rs);
+        a->done++;
+        a->walks += rs.n_walks;
+        if (now_s() - t0 > a->seconds) break;
+    }
+    a->elapsed = now_s() - t0;
+    free(reserve); free(residue); free(ppr); free(o1); free(o2); free(ws.idx); free(ws.q);
+    return NULL;
+}
+int64_t orc_query_many(int32_t n, const int64_t *row_ptr, const int32_t *col, const int32_t *sources, int64_t nsrc,
+                       double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                       const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
+                       uint64_t *walks) {
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    many_arg *args = (many_arg *)calloc((size_t)threads, sizeof(many_arg));
+    for (int t = 0; t < threads; t++) {
+        many_arg *a = &args[t];
+        a->n = n; a->row_ptr = row_ptr; a->col = col; a->sources = sources; a->nsrc = nsrc;
+        a->rmax = rmax; a->omega = omega; a->alpha = alpha; a->opt = opt; a->seed = seed;
+        a->rw_idx = rw_idx; a->off = off; a->cnt = cnt; a->tid = t; a->threads = threads; a->seconds = seconds;
+        if (pthread_create(&th[t], NULL, many_worker, a) != 0) { threads = t; break; }
+    }
+    int64_t done = 0;
+    uint64_t w = 0;
+    double el = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        done += args[t].done; w += args[t].walks;
+        if (args[t].elapsed > el) el = args[t].elapsed;
+    }
+    if (elapsed) *elapsed = el;
+    if (walks) *walks = w;
+    free(th); free(args);
+    return done;
 }
 
 /* ------------------------------------------------------------------- top-k */

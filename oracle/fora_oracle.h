@@ -99,6 +99,11 @@ int orc_refine(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s,
                const uint64_t *off, const uint64_t *cnt, double *ppr, orc_refine_stats *st);
 
 /* ---- fora_query_basic: query.h:841-907 (non --balanced) ---- */
+/* the query loop on `threads` host threads for `seconds` at most (bench.py's all-core baseline): queries finished */
+int64_t orc_query_many(int32_t n, const int64_t *row_ptr, const int32_t *col, const int32_t *sources, int64_t nsrc,
+                       double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                       const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
+                       uint64_t *walks);
 int orc_query(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
               double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
               const uint64_t *off, const uint64_t *cnt, double *ppr, orc_push_stats *pst,

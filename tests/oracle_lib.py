@@ -220,6 +220,19 @@ def query(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None):
                      n_idx_hit=rs.n_idx_hit, walk_steps=rs.walk_steps)
 
 
+def query_many(g, sources, rmax, omega, threads, seconds, alpha=0.2, opt=False, seed=0, index=None):
+    """The query loop on `threads` host threads (pthreads inside the oracle, private buffers per thread) for at most
+    `seconds`: (queries finished, wall seconds, walks)."""
+    src = np.ascontiguousarray(sources, dtype=np.int32)
+    a, b, c = _idx_args(index)
+    el, walks = C.c_double(0), C.c_uint64(0)
+    f = lib().orc_query_many
+    f.restype = C.c_int64
+    done = f(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), _p(src), C.c_int64(src.size), _d(rmax), _d(omega), _d(alpha),
+             C.c_int(int(opt)), C.c_uint64(seed), a, b, c, C.c_int(int(threads)), _d(seconds), C.byref(el), C.byref(walks))
+    return int(done), float(el.value), int(walks.value)
+
+
 def topk_query(g, s, k, epsilon, alpha=0.2, rmax_scale=1.0, seed=0, index=None, want_ppr=False):
     ids = np.zeros(k, dtype=np.int32)
     sc = np.zeros(k, dtype=np.float64)

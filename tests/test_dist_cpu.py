@@ -93,6 +93,17 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert one["n_gpus"] == 1 and one["queries_total_per_step"] == 5 and one["ranks"]["world_size_seen"] == 1
 
 
+def test_bench_eight_ranks_config5_shape():
+    """Pre-flight of the driver's 8-GPU run of BASELINE config 5 (Twitter-2010 top-k, k = 500, 1000 sources sharded over the
+    node): 8 gloo ranks through bench.py's own launcher -- 125 sources per rank, the gathered lists in global query order,
+    and 6 000 000 bytes per step through the all-gather (8 x 125 x 500 x (4 + 8))."""
+    line = _bench("--gpus", "8", "--scaling", "strong", "--queries", "1000", "--topk", "500")
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["queries_total_per_step"] == 1000
+    assert line["queries_per_rank"] == {"min": 125, "max": 125}
+    assert line["gather_in_global_order"] is True and line["gather_bytes_per_step"] == 6_000_000
+    assert line["ranks"]["world_size_seen"] == 8
+
+
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--plumbing-only", "--gpus", "4"],

@@ -346,3 +346,18 @@ def test_twin_threshold_rounds_keep_the_push_invariants(oracle, small_dangling, 
         oracle.twin_set_round_div(0)
     again = oracle.twin_push(g, int(srcs[0]), rmax)
     assert (again["residue"] == plain[0]["residue"]).all() and again["relax"] == plain[0]["relax"]
+
+
+def test_query_many_matches_single_queries(oracle, tiny):
+    """orc_query_many (bench.py's all-core CPU baseline): the query loop on several pthreads with private buffers does the
+    same work as one orc_query per source."""
+    from fora_amd import synth
+    g = tiny
+    rmax, omega = oracle.fora_setting(g.n, g.m, 0.5)
+    srcs = synth.query_set(g.n, 24, 7)
+    walks = sum(oracle.query(g, int(s), rmax, omega, seed=3)[1]["n_walks"] for s in srcs)
+    for threads in (1, 3):
+        done, dt, w = oracle.query_many(g, srcs, rmax, omega, threads, 60.0, seed=3)
+        assert done == len(srcs) and w == walks and dt > 0
+    done, _, _ = oracle.query_many(g, srcs, rmax, omega, 2, 0.0, seed=3)  # budget spent at once: one query per thread
+    assert done == 2

@@ -3,7 +3,7 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$R"; mkdir -p gpurun_out
 timeout 1500 python3 -m pytest tests/test_hip_parity_gpu.py -x -q -m gpu -k "deferral or push_paths or query_bit" > gpurun_out/ab_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/ab_tests.log
-run() { echo "== $*"; env "$@" python3 tools/pushbench.py --mode query --reps 3 $LIBS | python3 -c "
+run() { echo "== $*"; python3 tools/pushbench.py --mode query --reps 3 $(for kv in "$@"; do echo --option $kv; done) $LIBS | python3 -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)
@@ -11,9 +11,9 @@ for l in sys.stdin:
     print('%-16s bin %.1f acc %.1f tail %.1f push %.1f | walk %.1f wacc %.1f alloc %.1f | batch %.1f | launches %.0f relax/q %.0f pops/q %.0f walks/q %.0f' % (d['lib'], d['bin_ms'], d['accum_ms'], d['tail_ms'], d['push_ms'], d['walk_ms'], d['walk_accum_ms'], d['walk_alloc_ms'], d['batch_ms'], d['launches'], d['relax_per_q'], d['pops_per_q'], d['walks_per_q']))
 "; }
 LIBS=""
-run FORA_HIP_DEFER=0
-run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=8192
-run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=16384
-run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=32768
-run FORA_HIP_DEFER=1 FORA_HIP_DEFER_MIN=50000
-run FORA_HIP_DEFER=2 FORA_HIP_DEFER_MIN=32768
+run defer=0
+run defer=1 defer_min=8192
+run defer=1 defer_min=16384
+run defer=1 defer_min=32768
+run defer=1 defer_min=50000
+run defer=2 defer_min=32768

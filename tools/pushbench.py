@@ -22,6 +22,9 @@ def child(args):
     eng.set_params(alpha=0.2, epsilon=0.5, seed=0x464F5241)
     if args.batch:
         eng.set_batch(args.batch)
+    for kv in args.option:  # engine knobs the environment does not reach (schedule knobs: rounds, round_div, defer, defer_min)
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
     srcs = synth.query_set(n, args.queries, 20261001)
     if args.mode == "idx":
         eng.build_index()
@@ -63,6 +66,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--mode", default="push", choices=["push", "query", "idx"])
     ap.add_argument("--dangling", default="none", choices=["none", "rmat"])
+    ap.add_argument("--option", action="append", default=[], help="name=value for fora_hip_set_option (repeatable)")
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -71,7 +75,7 @@ def main():
     for lib in libs:
         env = dict(os.environ, FORA_HIP_LIB=os.path.abspath(lib))
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--graph", args.graph, "--queries", str(args.queries),
-               "--reps", str(args.reps), "--batch", str(args.batch), "--mode", args.mode, "--dangling", args.dangling]
+               "--reps", str(args.reps), "--batch", str(args.batch), "--mode", args.mode, "--dangling", args.dangling] + [x for kv in args.option for x in ("--option", kv)]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
         sys.stdout.write(r.stdout)
         if r.returncode:
