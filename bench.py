@@ -437,16 +437,17 @@ def run_workload(args, ctx, light=False):
     # roofline of the push kernels: ALGORITHMIC bytes = 52 B per pop + 24 B per edge relaxation of the
     # sequential FIFO oracle; relaxations the level-synchronous schedule adds on top are
     # not credited.  Duration: HIP events around every launch.
-    if tm["push_expand_launches"]:
+    if tm["push_expand_launches"] or tm.get("push_team_launches", 0):
         e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
         p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
-        launches = tm["push_expand_launches"] + tm["push_tail_launches"]  # bin-kernel launches (levels x passes) + the tail launch per batch
-        bucketed = tm["push_accum_launches"] > 0
+        team = tm.get("push_team_launches", 0) > 0  # k_push_team: ONE launch per batch runs every level (fora_team.h)
+        launches = tm["push_expand_launches"] + tm["push_tail_launches"] + tm.get("push_team_launches", 0)  # bin-kernel launches (levels x passes) / team launches + the tail launch per batch
+        bucketed = tm["push_accum_launches"] > 0 or team
         # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
         # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
         # relaxation, credited once against the sum of both kernels' durations
         alg_bytes = (24.0 * e_unit + (52.0 * p_unit if bucketed else 0.0)) * q_timed
-        step_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"]
+        step_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"] + tm.get("push_team_ms", 0.0)
         avg_ms = step_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -458,7 +459,8 @@ def run_workload(args, ctx, light=False):
             # WRITE_SIZE in separate runs, KiB -> bytes; MI355X guide: FETCH_SIZE may under-report wide
             # coalesced reads by up to 2x on gfx950 -- calibration on known byte counts: profiles/r03_pmc_calibration.txt)
             pmc = json.load(open(tpath))
-            prefixes = (["fora::k_pushq_bin", "fora::k_accum<false", "fora::k_push_tail"] if bucketed else ["fora::k_push_expand"])
+            prefixes = (["fora::k_push_team", "fora::k_push_tail"] if team else
+                        ["fora::k_pushq_bin", "fora::k_accum<false", "fora::k_push_tail"] if bucketed else ["fora::k_push_expand"])
             keys = [k for k in pmc if any(k.startswith(p) for p in prefixes)]
             lead = [k for k in pmc if k.startswith(prefixes[0])]
             if lead and all("FETCH_SIZE_bytes_total" in pmc[k] for k in keys):
@@ -473,9 +475,13 @@ def run_workload(args, ctx, light=False):
                 traffic_upper = sum(2 * pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
                                     for k in keys) / max(1, n_launch)
                 traffic_note = pmc.get("_note")
-        by_kernel = {("k_pushq_bin" if bucketed else "k_push_expand"): tm["push_expand_ms"] / max(1, tm["push_expand_launches"])}
-        if bucketed:
+        by_kernel = {}
+        if tm["push_expand_launches"]:
+            by_kernel["k_pushq_bin" if bucketed else "k_push_expand"] = tm["push_expand_ms"] / max(1, tm["push_expand_launches"])
+        if tm["push_accum_launches"]:
             by_kernel["k_accum<false>"] = tm["push_accum_ms"] / max(1, tm["push_accum_launches"])
+        if team:
+            by_kernel["k_push_team"] = tm["push_team_ms"] / tm["push_team_launches"]
         if tm["push_tail_launches"]:
             by_kernel["k_push_tail"] = tm["push_tail_ms"] / tm["push_tail_launches"]
         if tm["push_pop_launches"]:
@@ -483,7 +489,8 @@ def run_workload(args, ctx, light=False):
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_upper_bound": traffic_upper, "traffic_source": traffic_note,
-            "kernel": ("fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
+            "kernel": ("fora::k_push_team (every level of a batch's push in one launch, residue resident in LDS)" if team else
+                       "fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
                        if bucketed else "fora::k_push_expand"),
             "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
             "algorithmic_bytes_per_launch": alg_bytes / launches,
@@ -499,6 +506,7 @@ def run_workload(args, ctx, light=False):
     walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
     out["phases"] = {
         "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
+        "push_team_ms": tm.get("push_team_ms", 0.0),
         "walk_alloc_ms": tm["walk_alloc_ms"], "walk_ms": tm["walk_ms"], "walk_accum_ms": tm["walk_accum_ms"], "other_ms": tm["other_ms"],
         "batch_ms": tm["batch_ms"], "levels_launched": tm["levels"],
         "walks": tm["walks"], "walk_steps": tm["walk_steps"],

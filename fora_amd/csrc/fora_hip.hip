@@ -750,9 +750,22 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 dp.pop_next = !(level_cap > 0 && L + 1 >= level_cap); // a capped run leaves the last crossing nodes unpopped
                 dp.launch_par = (int32_t)(c->bin_launches++ & 1);
                 int h = ev_begin(c, 1);
-                if (d.wide && c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_HUGE>, dim3(xb, nq), dim3(BIN_THREADS_HUGE), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
-                else if (d.wide) hipLaunchKernelGGL(k_pushq_bin<MAX_BINS_WIDE>, dim3(xb, nq), dim3(BIN_THREADS_WIDE), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
-                else hipLaunchKernelGGL(k_pushq_bin<MAX_BINS>, dim3(xb, nq), dim3(BLOCK), dp.col_hub ? (size_t)dp.hubs * 8 : 0, c->stream, dp, L);
+                {
+                    const size_t hub_lds = dp.col_hub ? (size_t)dp.hubs * 8 : 0;
+                    const bool hub = dp.col_hub != nullptr, split = dp.row_split != nullptr, sched = dp.rounds > 1 || dp.defer_k > 0;
+#define FORA_BIN_LAUNCH(NBV, NT, HUBV, SPLITV, SCHEDV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, SPLITV, SCHEDV>), dim3(xb, nq), dim3(NT), hub_lds, c->stream, dp, L)
+#define FORA_BIN_PICK(NBV, NT) do { \
+                    if (sched) FORA_BIN_LAUNCH(NBV, NT, true, true, true); /* schedule experiments: the everything instantiation */ \
+                    else if (hub && split) FORA_BIN_LAUNCH(NBV, NT, true, true, false); \
+                    else if (hub) FORA_BIN_LAUNCH(NBV, NT, true, false, false); \
+                    else if (split) FORA_BIN_LAUNCH(NBV, NT, false, true, false); \
+                    else FORA_BIN_LAUNCH(NBV, NT, false, false, false); } while (0)
+                    if (d.wide && c->pbins > MAX_BINS_WIDE) FORA_BIN_PICK(MAX_BINS_HUGE, BIN_THREADS_HUGE);
+                    else if (d.wide) FORA_BIN_PICK(MAX_BINS_WIDE, BIN_THREADS_WIDE);
+                    else FORA_BIN_PICK(MAX_BINS, BLOCK);
+#undef FORA_BIN_PICK
+#undef FORA_BIN_LAUNCH
+                }
                 ev_end(c, h);
                 h = ev_begin(c, 6);
                 if (d.wide) hipLaunchKernelGGL((k_accum<false, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L);

@@ -468,8 +468,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 product each (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: the walk kernels are
+        // bound by these quarter-rate multiplies (profiles/r04_walk_bound.txt)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
@@ -704,7 +706,9 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // (increment table `inc_tab`), a wide one carries the increment.  Measured and dropped: gathering with
 // consecutive lanes on consecutive edges through an LDS address table, carrying rowinfo in the frontier entry, and
 // loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
-template <int NB>
+// HUB: the graph has a hub copy (Dev::col_hub); SPLIT: several bin passes per level over row-split offsets; ROUNDS: threshold
+// rounds / bounded deferral bookkeeping.  The plain instantiation does not carry what it does not use (spills).
+template <int NB, bool HUB, bool SPLIT, bool SCHED>
 __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int L) {
     constexpr int NT = BinThreads<NB>::value; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
     const int q = blockIdx.y;
@@ -713,17 +717,17 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     const bool first_pass = d.bin_lo == 0; // graphs with more than pbins bins run several bin/accum passes per level
     if (first_pass && blockIdx.x == 0 && threadIdx.x == 0) {
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
-        d.fl_count[par ^ 1][q * CSTRIDE + 2] = 0; // ... and so does the count of nodes this level defers
+        if (SCHED) d.fl_count[par ^ 1][q * CSTRIDE + 2] = 0; // ... and so does the count of nodes this level defers
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
         if (count) d.qs[q].levels++;          // levels in which the slot popped (this thread is the only writer in a launch)
-        if (d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
+        if (SCHED && d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
     }
     constexpr bool WIDE = NB > MAX_BINS;
     if (WIDE && blockIdx.x == 0 && threadIdx.x == 0) d.tile_ctr[d.launch_par ^ 1][q * CSTRIDE] = 0; // for the next launch
     if (!count) return;
     // hub pre-aggregation (see Dev::col_hub): the same predicate in k_accum decides whether hubsum is read
     extern __shared__ unsigned long long s_hub[]; // [d.hubs] when hubmode
-    const bool hubmode = d.col_hub && count >= d.hub_min;
+    const bool hubmode = HUB && d.col_hub && count >= d.hub_min;
     if (hubmode) for (uint32_t i = threadIdx.x; i < d.hubs; i += BinThreads<NB>::value) s_hub[i] = 0;
     const int32_t *colsrc = hubmode ? d.col_hub : d.col_push;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
@@ -786,7 +790,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                 if (rsv_add) d.ppr[slab + v] = rsv_old + rsv_add; // algo.h:986-989 (only this lane owns (q, v))
                 acc_res += rsv_add; acc_dang += dang; acc_pops++; acc_relax += deg;
             }
-            if (d.row_split) { // only the part of the (sorted) row whose targets belong to this pass
+            if (SPLIT && d.row_split) { // only the part of the (sorted) row whose targets belong to this pass
                 const uint32_t *sp = d.row_split + (uint64_t)v * (d.npass + 1) + d.pass;
                 beg += sp[0];
                 deg = sp[1] - sp[0];
@@ -2707,14 +2711,24 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                     done = (int32_t)cur;
                     active = false;
                 } else {
+#if defined(FORA_DG_FAKE_STEP0) // diagnostic only (wrong results): what the kernel would take if the first step of every walk hit L1
+                    cur = t == 0 ? move(cur & 1023u, startp, rw[1]) : move(cur, startp, rw[1]);
+#elif defined(FORA_DG_FAKE_ALL) // diagnostic only: every step's gather from a 4-KB window (the kernel's floor without misses)
+                    cur = move(cur & 1023u, startp, rw[1]);
+#else
                     cur = move(cur, startp, rw[1]);
+#endif
                     steps++;
                     if (rw[2] < d.alpha32) {
                         t++;
                         done = (int32_t)cur;
                         active = false;
                     } else {
+#if defined(FORA_DG_FAKE_ALL)
+                        cur = move(cur & 1023u, startp, rw[3]);
+#else
                         cur = move(cur, startp, rw[3]);
+#endif
                         t += 2;
                         steps++;
                     }

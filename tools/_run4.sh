@@ -1,0 +1,2 @@
+timeout 900 python -m pytest tests/test_hip_parity_gpu.py -x -q -m gpu -k "walk or query_bit or index" 2>&1 | tail -2
+python3 tools/pushbench.py --mode query --reps 3 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('walk_ms','walk_accum_ms','walk_alloc_ms','push_ms','batch_ms')})"
