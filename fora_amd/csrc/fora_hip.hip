@@ -54,12 +54,10 @@ struct Tunables {
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
-    int64_t team = -1;           // graphs of the narrow layout push with k_push_team (residue resident in the LDS of a team of workgroups, fora_team.h): 1 always, 0 never (bucketed kernels),
-                                 // -1: when more than a fifth of the nodes are dangling -- their mass returns to the source every level and the push ends in hundreds of tiny levels, which cost
-                                 // the team a barrier each and the bucketed path a launch pair or a k_push_tail level (ws-sized R-MAT with 52 % dangling nodes, push of 1000 queries: 46.8 ms against 66.5);
-                                 // on the headline graph (no dangling nodes) the bucketed kernels are faster (75.3 ms against 81.9).  Same bits either way.
+    int64_t team = 0;            // 1: graphs of the narrow layout push with k_push_team (residue resident in the LDS of a team of workgroups, fora_team.h); 0 (default): the bucketed kernels.
+                                 // Same bits either way.  Measured, push of 1000 queries: ws-sized graph 81.9 ms against 75.3 bucketed; R-MAT variant with 52 % dangling nodes (483 sources with out-edges) 46.6 against 38.
     int64_t team_size = 0;       // members per team (a power of two up to 32); 0: the fewest whose LDS holds the graph; read by set_graph
-    int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096, never on graphs with more than a fifth of dangling nodes
+    int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
     int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
@@ -124,7 +122,6 @@ struct fora_ctx {
     uint16_t *d_team_deg16 = nullptr;
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
     bool team_checked = false, team_wanted = false;  // ensure_team has looked at this graph with these options
-    double dangling_frac = 0;        // share of the nodes without out-edges
     uint64_t team_cap = 0;           // message slots per (team, parity)
     // ... and its workspace
     uint32_t *d_team_msg = nullptr;
@@ -409,8 +406,7 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 // col that names every target as (owner, local id) and the exact bucket capacities.  Built on first use and whenever
 // the `team` / `team_size` options ask for another shape.
 static bool want_team(const fora_ctx *c) {
-    const bool on = c->opt_.team == 1 || (c->opt_.team < 0 && c->dangling_frac > 0.2);
-    return on && want_binned(c) && !want_wide(c) && c->nnz > 0;
+    return c->opt_.team == 1 && want_binned(c) && !want_wide(c) && c->nnz > 0;
 }
 int ensure_team(fora_ctx *c) {
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
@@ -855,7 +851,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 4 * 16 * 2;
     // frontier size of a slot at which k_push_tail (one workgroup per slot, global atomics) takes over; 0: never
-    const int64_t tail_auto = c->dangling_frac > 0.2 ? 0 : 4096; // (dangling graphs: the long cascade of small levels is cheaper inside the team, ws-sized R-MAT 46.8 ms against 51.2)
+    const int64_t tail_auto = 4096;
     a.tail_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_tail < 0 ? tail_auto : c->opt_.team_tail, 0), 0x7FFFFFFF);
     if (c->opt_.tail == 0) a.tail_max = 0; // `tail` 0 keeps k_push_tail out of every path (tests)
     a.tail_always = c->opt_.tail_always == 1 ? 1u : 0u;
@@ -1160,7 +1156,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
@@ -1181,12 +1177,34 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
     if (nq < 0 || (nq && !sources)) return fail(c, FORA_E_ARG, "bad sources");
     if (with_idx && !c->have_index) return fail(c, FORA_E_ARG, "with_idx without an index (build or set one)");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_workspace(c, nq, c->omega);
-    if (rc) return rc;
+    for (int i = 0; i < nq; i++)
+        if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
     const uint64_t n = (uint64_t)c->n;
+    // A dangling source is its own whole answer (algo.h:961-965: reserve[s] = 1, rsum = 0, no push, no walks): it is
+    // written here and never takes a slot.  (On the R-MAT variant with 52 % dangling nodes half of a batch's slots were
+    // such sources, and every level launch and the tail kernel carried their empty workgroups: push of 1000 queries
+    // 66.5 ms against 38 for the 483 others alone.)
+    std::vector<int32_t> live_src;
+    std::vector<int> live_at; // position of live source i in the caller's arrays
+    for (int i = 0; i < nq; i++) {
+        const int32_t s = sources[i];
+        if (c->h_row_ptr[s + 1] != c->h_row_ptr[s]) { live_src.push_back(s); live_at.push_back(i); continue; }
+        if (stats) {
+            fora_query_stats &o = stats[i];
+            memset(&o, 0, sizeof(o));
+            o.ppr_sum_fix = FIX_ONE; o.dangling_source = 1; o.rmax_used = c->rmax; o.push_rounds = 1;
+        }
+        if (ppr_d) { double *row = ppr_d + (uint64_t)i * n; memset(row, 0, n * 8); row[s] = 1.0; }
+        if (ppr_fix) { uint64_t *row = ppr_fix + (uint64_t)i * n; memset(row, 0, n * 8); row[s] = FIX_ONE; }
+        if (residue_fix) memset(residue_fix + (uint64_t)i * n, 0, n * 8);
+    }
+    const int nl = (int)live_src.size();
+    if (nl == 0) return FORA_OK;
+    int rc = ensure_workspace(c, nl, c->omega);
+    if (rc) return rc;
     // second lane when there is more than one batch to run
     fora_ctx *lanes[2] = {c, c};
-    if (nq > c->B && c->opt_.pipeline == 1) { // opt-in: measured no gain on ws (kernels time-slice)
+    if (nl > c->B && c->opt_.pipeline == 1) { // opt-in: measured no gain on ws (kernels time-slice)
         rc = sync_twin(c);
         if (rc) return rc;
         rc = ensure_workspace(c->twin, c->B, c->omega);
@@ -1195,29 +1213,40 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
     }
     struct Pending { fora_ctx *lane; int b0, nb; };
     std::vector<Pending> inflight;
+    std::vector<fora_query_stats> st_tmp;
     auto finish = [&](const Pending &p) -> int {
         int r = batch_finish(p.lane);
         if (r) { if (p.lane != c) c->err = p.lane->err; return r; }
-        if (stats) fill_stats(p.lane, p.nb, stats + p.b0);
-        const uint64_t bytes = (uint64_t)p.nb * n * 8;
-        if (ppr_d) {
-            // u64 and f64 have the same size: copy raw, convert in place on the host
-            double *dst = ppr_d + (uint64_t)p.b0 * n;
-            HIPCHK(c, hipMemcpy(dst, p.lane->d_ppr, bytes, hipMemcpyDeviceToHost));
-            uint64_t *raw = (uint64_t *)dst;
-            for (uint64_t i = 0; i < (uint64_t)p.nb * n; i++) {
-                uint64_t u = raw[i];
-                dst[i] = std::ldexp((double)u, -62);
-            }
+        if (stats) {
+            st_tmp.resize((size_t)p.nb);
+            fill_stats(p.lane, p.nb, st_tmp.data());
+            for (int i = 0; i < p.nb; i++) stats[live_at[(size_t)p.b0 + i]] = st_tmp[(size_t)i];
         }
-        if (ppr_fix) HIPCHK(c, hipMemcpy(ppr_fix + (uint64_t)p.b0 * n, p.lane->d_ppr, bytes, hipMemcpyDeviceToHost));
-        if (residue_fix) HIPCHK(c, hipMemcpy(residue_fix + (uint64_t)p.b0 * n, p.lane->d_residue, bytes, hipMemcpyDeviceToHost));
+        // slots i .. j - 1 of the batch whose places in the caller's arrays are consecutive too: one copy
+        for (int i = 0; i < p.nb && (ppr_d || ppr_fix || residue_fix);) {
+            int j = i + 1;
+            while (j < p.nb && live_at[(size_t)p.b0 + j] == live_at[(size_t)p.b0 + j - 1] + 1) j++;
+            const uint64_t at = (uint64_t)live_at[(size_t)p.b0 + i] * n, from = (uint64_t)i * n, cnt = (uint64_t)(j - i) * n;
+            if (ppr_d) {
+                // u64 and f64 have the same size: copy raw, convert in place on the host
+                double *dst = ppr_d + at;
+                HIPCHK(c, hipMemcpy(dst, p.lane->d_ppr + from, cnt * 8, hipMemcpyDeviceToHost));
+                uint64_t *raw = (uint64_t *)dst;
+                for (uint64_t x = 0; x < cnt; x++) {
+                    uint64_t u = raw[x];
+                    dst[x] = std::ldexp((double)u, -62);
+                }
+            }
+            if (ppr_fix) HIPCHK(c, hipMemcpy(ppr_fix + at, p.lane->d_ppr + from, cnt * 8, hipMemcpyDeviceToHost));
+            if (residue_fix) HIPCHK(c, hipMemcpy(residue_fix + at, p.lane->d_residue + from, cnt * 8, hipMemcpyDeviceToHost));
+            i = j;
+        }
         return FORA_OK;
     };
     int k = 0;
-    const int per = even_batch(nq, c->B);
-    for (int b0 = 0; b0 < nq; b0 += per, k++) {
-        const int nb = std::min(per, nq - b0);
+    const int per = even_batch(nl, c->B);
+    for (int b0 = 0; b0 < nl; b0 += per, k++) {
+        const int nb = std::min(per, nl - b0);
         fora_ctx *lane = lanes[k & 1];
         // the lane's previous batch must be drained before its workspace is reused
         for (size_t i = 0; i < inflight.size();) {
@@ -1227,7 +1256,7 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
                 inflight.erase(inflight.begin() + (long)i);
             } else i++;
         }
-        rc = batch_begin(lane, sources + b0, nb, with_idx != 0, flags);
+        rc = batch_begin(lane, live_src.data() + b0, nb, with_idx != 0, flags);
         if (rc) { if (lane != c) c->err = lane->err; return rc; }
         inflight.push_back({lane, b0, nb});
     }
@@ -1525,10 +1554,8 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->bk_scale = 1;
     std::vector<uint64_t> rowinfo((size_t)n);
     std::vector<uint32_t> deg((size_t)n);
-    int64_t n_dangling = 0;
     for (int32_t v = 0; v < n; v++) {
         const uint64_t dg = (uint64_t)(row_ptr[v + 1] - row_ptr[v]);
-        n_dangling += dg == 0;
         if (dg > 0xFFFFFFFFull) return fail(c, FORA_E_ARG, "out-degree over 2^32");
         deg[v] = (uint32_t)dg;
         rowinfo[v] = ((uint64_t)row_ptr[v] << 24) | std::min<uint64_t>(dg, DEG_SAT);
@@ -1563,7 +1590,6 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     }
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
-    c->dangling_frac = (double)n_dangling / (double)n;
     if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
     if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
     return FORA_OK;
