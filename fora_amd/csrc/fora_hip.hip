@@ -715,6 +715,8 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
             if (levels_run) *levels_run = 1;
             hipError_t e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("push: ") + hipGetErrorString(e));
+            e = hipGetLastError(); // (the launch check of the level loop's epilogue)
+            if (e != hipSuccess) return fail(c, FORA_E_HIP, std::string("push launch: ") + hipGetErrorString(e));
             return FORA_OK;
         }
     }
@@ -1397,8 +1399,13 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     const int32_t n = c->n;
     const int64_t nnz = c->nnz;
     const int64_t wide_auto = nnz <= (1ll << 28) ? 2048 : 0;
-    const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : c->opt_.hubs, 0), 6144); // 48 KB of dynamic LDS at most
+    // the hub sums live in the bin kernel's dynamic LDS next to its static arrays: 48 KB in the narrow and the 512-thread
+    // wide kernel, 32 KB in the 1024-thread one (its stage of 12 edges per thread takes 122 of the 160 KB)
+    const uint64_t nbins_all = bins_of(c);
+    const int64_t lds_cap = !want_wide(c) ? 6144 : nbins_all > (uint64_t)MAX_BINS_WIDE ? 4096 : 6144;
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : c->opt_.hubs, 0), lds_cap);
     if (want == 0 || nnz == 0 || c->opt_.direct == 1) return FORA_OK;
+    if (want_wide(c) && (int64_t)nbins_all > (int64_t)want_pass_bins(c, (int)nbins_all)) return FORA_OK; // several bin passes per level: the passes read the row-sorted copy, hubs are never used (make_dev)
     std::vector<uint32_t> indeg((size_t)n, 0);
     for (int64_t e = 0; e < nnz; e++) indeg[(size_t)col[e]]++;
     std::vector<uint32_t> order((size_t)n);

@@ -66,7 +66,7 @@ constexpr int BIN_EPT = 8; // edges per thread per chunk in k_pushq_bin / k_walk
 #endif
 // wide layouts: every (chunk, bin) run of messages is padded with null words to a multiple of this many messages, so
 // that it starts and ends on a 32-byte sector boundary (4 x 8 bytes).  Writes move whole sectors: an unaligned run of
-// R bytes costs (R + 24) / 32 sectors (profiles/r03_pmc_calibration.txt), and aligned sector writes are several times
+// R bytes costs (R + 24) / 32 sectors (profiles/r04_pmc_calibration.txt), and aligned sector writes are several times
 // faster than unaligned ones.  k_accum skips null words.  1: no padding.
 #ifndef FORA_RUN_PAD_WIDE
 #define FORA_RUN_PAD_WIDE 1

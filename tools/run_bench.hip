@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_runs(uint64_t *buf, uint64_t words, uin
             uint64_t v[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) v[u] = 0;
-            if (o + lane < run_words) {
+            if (o + lane < run_words && (threadIdx.x & 63) < (64 / lpr) * lpr) { // (the 64 mod lpr leftover lanes of a wave would form a partial run the host does not count)
                 if (MODE != WRITE) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) v[u] = buf[base[u] + o + lane];
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_calib(W *buf, uint64_t words, uint32_t 
         for (int u = 0; u < 4; u++) base[u] = (mix(wave * 1000003ull + (uint64_t)(s + u)) % slots) * run_words;
         for (uint32_t o = 0; o < run_words; o += 64) {
             W v[4] = {0, 0, 0, 0};
-            if (o + lane < run_words) {
+            if (o + lane < run_words && (threadIdx.x & 63) < (64 / lpr) * lpr) { // (leftover lanes: see k_runs)
                 if (MODE != WRITE) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) v[u] = buf[base[u] + o + lane];
