@@ -54,8 +54,9 @@ struct Tunables {
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
-    int64_t team = 0;            // 1: graphs of the narrow layout push with k_push_team (residue resident in the LDS of a team of workgroups, fora_team.h); 0 (default): the bucketed kernels.
-                                 // Same bits either way.  Measured, push of 1000 queries: ws-sized graph 81.9 ms against 75.3 bucketed; R-MAT variant with 52 % dangling nodes (483 sources with out-edges) 46.6 against 38.
+    int64_t team = -1;           // graphs of the narrow layout push with k_push_team (a slot's residue resident in the LDS of a team of workgroups, fora_team.h): 1 always, 0 never (the bucketed
+                                 // kernels), -1 (default): unless more than a fifth of the nodes are dangling.  Same bits either way.  Measured, push of 1000 queries: ws-sized graph 74.3 ms against
+                                 // 77.8 bucketed; R-MAT variant with 52 % dangling nodes (483 sources with out-edges, heavier pushes, 30 slots per team in a row) 47.3 against 41.3
     int64_t team_size = 0;       // members per team (a power of two up to 32); 0: the fewest whose LDS holds the graph; read by set_graph
     int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
@@ -122,6 +123,7 @@ struct fora_ctx {
     uint16_t *d_team_deg16 = nullptr;
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
     bool team_checked = false, team_wanted = false;  // ensure_team has looked at this graph with these options
+    double dangling_frac = 0;        // share of the nodes without out-edges
     uint64_t team_cap = 0;           // message slots per (team, parity)
     // ... and its workspace
     uint32_t *d_team_msg = nullptr;
@@ -406,7 +408,8 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 // col that names every target as (owner, local id) and the exact bucket capacities.  Built on first use and whenever
 // the `team` / `team_size` options ask for another shape.
 static bool want_team(const fora_ctx *c) {
-    return c->opt_.team == 1 && want_binned(c) && !want_wide(c) && c->nnz > 0;
+    const bool on = c->opt_.team == 1 || (c->opt_.team < 0 && c->dangling_frac <= 0.2);
+    return on && want_binned(c) && !want_wide(c) && c->nnz > 0;
 }
 int ensure_team(fora_ctx *c) {
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
@@ -428,7 +431,7 @@ int ensure_team(fora_ctx *c) {
     std::vector<uint32_t> cntm;
     uint32_t R = 0;
     for (;; T *= 2) {
-        if (T > (uint32_t)TEAM_MAX || T > (uint32_t)std::max(1, c->prop.multiProcessorCount)) return FORA_OK; // too large for the team path
+        if (T > (uint32_t)TEAM_MAX || T > (uint32_t)std::max(1, c->prop.multiProcessorCount * TEAM_WGS_PER_CU)) return FORA_OK; // too large for the team path
         cntm.assign(T, 0);
         for (size_t v = 0; v < n; v++) if (indeg[v]) cntm[(v >> 6) % T]++;
         R = (*std::max_element(cntm.begin(), cntm.end()) + 63) / 64 * 64;
@@ -540,7 +543,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         if (c->hubs && c->hub_shift == bin_shift(c)) HIPCHK(c, hipMalloc(&c->d_hubsum, (size_t)B * p.sub * c->hubs * 8));
         if (c->team_T) { // team push: message buffers of every team (two parities), bucket counts, control words
             const uint32_t T = c->team_T;
-            uint32_t nteams = std::max<uint32_t>(1, (uint32_t)c->prop.multiProcessorCount / T);
+            uint32_t nteams = std::max<uint32_t>(1, (uint32_t)c->prop.multiProcessorCount * TEAM_WGS_PER_CU / T);
             if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
@@ -549,7 +552,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
-            HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 4 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
+            HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 5 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
         }
     } else {
@@ -851,14 +854,14 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
-    a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 4 * 16 * 2;
+    a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;
     // frontier size of a slot at which k_push_tail (one workgroup per slot, global atomics) takes over; 0: never
     const int64_t tail_auto = 4096;
     a.tail_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_tail < 0 ? tail_auto : c->opt_.team_tail, 0), 0x7FFFFFFF);
     if (c->opt_.tail == 0) a.tail_max = 0; // `tail` 0 keeps k_push_tail out of every path (tests)
     a.tail_always = c->opt_.tail_always == 1 ? 1u : 0u;
     const uint32_t grid = nteams * T;
-    a.xcd = (c->opt_.team_xcd == 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? 1u : 0u;
+    a.xcd = (c->opt_.team_xcd >= 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? (uint32_t)c->opt_.team_xcd : 0u;
     a.stamps = c->d_stamps;
     a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
     const size_t lds = ((size_t)a.R + 1) * 8;
@@ -866,7 +869,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TEAM_R_CAP + 1) * 8)));
         c->team_attr = true;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 4 * 16 * 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 5 * 16 * 2) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(a.slot_seq, 0xFF, (size_t)nteams * ((size_t)d.nq + 2) * 4, c->stream));
     int h = ev_begin(c, 10);
     hipLaunchKernelGGL(k_push_team, dim3(grid), dim3(TEAM_THREADS), lds, c->stream, a);
@@ -1158,7 +1161,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap;
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
@@ -1561,8 +1564,10 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->bk_scale = 1;
     std::vector<uint64_t> rowinfo((size_t)n);
     std::vector<uint32_t> deg((size_t)n);
+    int64_t n_dangling = 0;
     for (int32_t v = 0; v < n; v++) {
         const uint64_t dg = (uint64_t)(row_ptr[v + 1] - row_ptr[v]);
+        n_dangling += dg == 0;
         if (dg > 0xFFFFFFFFull) return fail(c, FORA_E_ARG, "out-degree over 2^32");
         deg[v] = (uint32_t)dg;
         rowinfo[v] = ((uint64_t)row_ptr[v] << 24) | std::min<uint64_t>(dg, DEG_SAT);
@@ -1597,6 +1602,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     }
     c->h_row_ptr.assign(row_ptr, row_ptr + n + 1);
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
+    c->dangling_frac = (double)n_dangling / (double)n;
     if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
     if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
     return FORA_OK;

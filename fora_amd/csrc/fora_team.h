@@ -42,10 +42,17 @@ namespace fora {
 
 constexpr int TEAM_MAX = 32;                  // members of a team (5 bits of a target word)
 constexpr int TEAM_LBITS = 15;                // bits of a local id
-constexpr int TEAM_THREADS = 1024;            // one workgroup per CU
+#ifndef FORA_TEAM_THREADS
+#define FORA_TEAM_THREADS 1024
+#endif
+constexpr int TEAM_THREADS = FORA_TEAM_THREADS; // 1024: one workgroup per CU; 512: two per CU (members of two different teams: one team's waits overlap the other's work)
+#ifndef FORA_TEAM_WGS_PER_CU
+#define FORA_TEAM_WGS_PER_CU (FORA_TEAM_THREADS == 1024 ? 1 : 2)
+#endif
+constexpr int TEAM_WGS_PER_CU = FORA_TEAM_WGS_PER_CU;
 constexpr int TEAM_NW = TEAM_THREADS / 64;
-constexpr int TEAM_NIT = 15;                  // sweep iterations at most (ids per thread): R <= 15 * 1024
-constexpr uint32_t TEAM_R_CAP = 15296;        // local ids per member at most: 8 * (R + 1) + the static LDS below <= 160 KiB
+constexpr uint32_t TEAM_R_CAP = TEAM_WGS_PER_CU == 1 ? 15296 : 7680; // local ids per member at most: 8 * (R + 1) + the static LDS below <= 160 KiB / workgroups per CU
+constexpr int TEAM_NIT = (TEAM_R_CAP + TEAM_THREADS - 1) / TEAM_THREADS; // sweep iterations at most (ids per thread): 15 (30 with 512 threads and one workgroup per CU)
 #ifndef FORA_TEAM_EPT
 #define FORA_TEAM_EPT 4
 #endif
@@ -85,12 +92,12 @@ struct TeamDev {
     uint32_t *msg;                 // [nteams][2][off[T * T]]
     uint64_t *inct;                // [nteams][2][T][R + 64] increment tables: entry e of member s = the increment of its e-th pop of the level
     uint32_t *cnt;                 // [nteams][2][T * T] messages in bucket (s -> d) this level
-    unsigned long long *sync;      // [nteams][4][16] barrier words, one 128-byte line each
+    unsigned long long *sync;      // [nteams][5][16] barrier words, one 128-byte line each; the fifth: the members' XCD census
     uint32_t *slot_seq;            // [nteams][nq + 2] slot taken by the team in its k-th turn (TEAM_EMPTY: not yet)
     uint32_t *ctl;                 // [0] next slot, [32] abort flag
     uint32_t tail_max;             // hand the slot to k_push_tail once its frontier is at most this (and has been larger); 0: never
     uint32_t tail_always;          // tests: do not wait for the frontier to have been larger
-    uint32_t xcd;                  // != 0: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
+    uint32_t xcd;                  // != 0: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only; the kernel checks where they really are); 2: the same, but always with the fences (tests)
     unsigned long long *stamps;    // diagnostic builds (-DFORA_STAMPS): cycles per phase of thread 0, summed over workgroups, [0..7]
     uint64_t timeout_ticks;        // wall_clock64 ticks (100 MHz) a member waits for its team before it gives up
 };
@@ -190,7 +197,7 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
 // Inside a level nothing but the consume -> sweep and the emit -> barrier seams is a workgroup barrier: the waves draw the
 // level's 64-id groups from a shared counter, collect the crossing nodes in a wave-private list and pop / emit them 64 at a
 // time on their own (prefix sums by wave scan), so the sixteen waves of a member overlap each other's memory round trips.
-__global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
+__global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev a) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
     extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id
     __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
     __shared__ uint32_t w_pref[TEAM_NW][65];                 // per wave: exclusive prefix of the out-degrees of the nodes of its batch
@@ -219,7 +226,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
     const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
     const uint64_t cap_total = a.off[T * T];
     const uint32_t *l2n = a.l2n + (uint64_t)me * R;
-    unsigned long long *sync = a.sync + (uint64_t)team * 4 * 16;
+    unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
     for (uint32_t l = tid; l <= R; l += TEAM_THREADS) res[l] = 0;
     if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
@@ -231,6 +238,30 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
         const uint32_t dv = ((uint32_t)it < nit && l < R) ? (uint32_t)a.deg16[(uint64_t)me * R + l] : 0u;
         if (it & 1) dgp[it >> 1] |= dv << 16; else dgp[it >> 1] = dv;
     }
+    // Do the team's members share an XCD?  Each adds 1 to the byte of its XCC id (HW_REG_XCC_ID) in the census word and
+    // waits for all T.  Members of one XCD share its L2: what a member has stored (and waited for: vmcnt(0)) is in that L2,
+    // and a load that bypasses L1 (sc1: relaxed agent-scope atomic load) sees it -- no release write-back of the L2 and no
+    // acquire invalidate per level (~1.7 us each and more with freshly dirtied lines, MI355X guide).  Otherwise: both fences.
+    if (tid == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *cw = &sync[4 * 16];
+        __hip_atomic_fetch_add(cw, 1ull << (8 * (xcc & 7u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long v = 0;
+        const bool ok = team_wait(a, a.err, [&] {
+            v = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t tot = 0;
+            for (int i = 0; i < 8; i++) tot += (uint32_t)(v >> (8 * i)) & 0xFFu;
+            return tot == T;
+        });
+        bool one = false;
+        for (int i = 0; i < 8; i++) one |= ((uint32_t)(v >> (8 * i)) & 0xFFu) == T;
+        s_F = (one && a.xcd != 2) ? 1u : 0u; // (xcd == 2: tests force the fenced form)
+        s_ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const bool same_xcd = s_F != 0;
     __syncthreads();
     TSTAMP_DECL
     uint32_t g = 0; // barriers this team has passed: message / count buffers by g & 1, barrier words by g & 3
@@ -271,7 +302,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                 const uint32_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
                 const uint64_t *tin = a.inct + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * tstride;
                 if (tid < 64) {
-                    const uint32_t c = (uint32_t)lane < T ? cin[(uint32_t)lane * T + me] : 0u;
+                    const uint32_t c = (uint32_t)lane < T ? __hip_atomic_load(&cin[(uint32_t)lane * T + me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; // (sc1: past L1, like every load of handed-over data)
                     uint32_t tot, tots;
                     const uint32_t ex = wave_excl_scan(c, tot);
                     const uint32_t exs = wave_excl_scan((c + 127u) >> 7, tots);
@@ -300,14 +331,18 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
                         const uint32_t n_s = s_cpre[lo + 1] - s_cpre[lo];
                         left[k] = (j < nseg && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
                         srcm[k] = lo;
-                        m[k] = *(const uint2 *)(min_ + (uint64_t)s_coff[lo] + (left[k] ? idx : 0u)); // (buckets hold a multiple of 16 words)
+                        {
+                            const unsigned long long mm = __hip_atomic_load((const unsigned long long *)(min_ + (uint64_t)s_coff[lo] + (left[k] ? idx : 0u)),
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (buckets hold a multiple of 16 words)
+                            m[k].x = (uint32_t)mm; m[k].y = (uint32_t)(mm >> 32);
+                        }
                     }
                     uint64_t va[CU], vb[CU];
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
-                        va[k] = tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u];
-                        vb[k] = tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u];
+                        va[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vb[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
@@ -324,7 +359,7 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             if (tid < TEAM_MAX) s_fill[tid] = 0;
             if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; }
             if (L > 0) {
-                constexpr int SG = 5; // LDS reads in flight together (TEAM_NIT = 3 * SG)
+                constexpr int SG = 5; // LDS reads in flight together
 #pragma unroll
                 for (int g0 = 0; g0 < TEAM_NIT; g0 += SG) {
                     if ((uint32_t)g0 < nit) { // wave-uniform
@@ -553,14 +588,18 @@ __global__ void __launch_bounds__(TEAM_THREADS) k_push_team(const TeamDev a) {
             __syncthreads();
             // ================= the team's barrier; the level's frontier size comes with it
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!same_xcd) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 unsigned long long *wd = &sync[(g & 3u) * 16];
                 __hip_atomic_fetch_add(wd, (1ull << 32) | (unsigned long long)s_ncross, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long v = 0;
                 const bool ok = team_wait(a, a.err, [&] { v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (uint32_t)(v >> 32) == T; });
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!same_xcd) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 if (me == 0) __hip_atomic_store(&sync[((g + 2) & 3u) * 16], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // dead since barrier g - 1
                 s_F = (uint32_t)v;
                 s_ok = ok ? 1u : 0u;
