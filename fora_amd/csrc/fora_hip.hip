@@ -120,6 +120,7 @@ struct fora_ctx {
     WalkDG dg{};
     // team push (fora_team.h): target copy of col, bucket offsets; built by set_graph for graphs of the narrow layout
     uint32_t *d_colt = nullptr, *d_team_off = nullptr, *d_team_n2l = nullptr, *d_team_l2n = nullptr;
+    uint64_t *d_team_rowl = nullptr, *d_team_rsvl = nullptr; // rows by local id (graph); reserve accumulators by local id (workspace)
     uint16_t *d_team_deg16 = nullptr;
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
     bool team_checked = false, team_wanted = false;  // ensure_team has looked at this graph with these options
@@ -131,6 +132,7 @@ struct fora_ctx {
     uint32_t *d_team_cnt = nullptr, *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
     uint32_t team_n = 0;             // teams of a launch
     bool team_attr = false;          // dynamic LDS limit of k_push_team raised
+    bool team_dirty = false;         // a launch ended with an error flag: its reserve accumulators (TeamDev::rsvl) may not be zero
 
     // params
     bool have_params = false;
@@ -240,7 +242,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -261,7 +263,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
-    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
+    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_rsvl); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -417,7 +419,7 @@ int ensure_team(fora_ctx *c) {
     const uint32_t force = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_size, 0), TEAM_MAX);
     if (c->team_checked && want == c->team_wanted && (!want || c->team_force == force)) return FORA_OK;
     c->team_checked = true; c->team_wanted = want;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16);
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl);
     c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_force = force;
     if (!want) return FORA_OK;
     const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
@@ -440,13 +442,16 @@ int ensure_team(fora_ctx *c) {
     }
     std::vector<uint32_t> n2l(n, TEAM_EMPTY), l2n((size_t)T * R, TEAM_EMPTY);
     std::vector<uint16_t> deg16((size_t)T * R, 0);
+    std::vector<uint64_t> rowl((size_t)T * R, 0);
     std::fill(cntm.begin(), cntm.end(), 0);
     for (size_t v = 0; v < n; v++) {
         if (!indeg[v]) continue;
         const uint32_t s = (uint32_t)((v >> 6) % T), l = cntm[s]++;
         n2l[v] = (s << TEAM_LBITS) | l;
         l2n[(size_t)s * R + l] = (uint32_t)v;
-        deg16[(size_t)s * R + l] = (uint16_t)std::min<int64_t>(c->h_row_ptr[v + 1] - c->h_row_ptr[v], 0xFFFF);
+        const int64_t dg = c->h_row_ptr[v + 1] - c->h_row_ptr[v];
+        deg16[(size_t)s * R + l] = (uint16_t)std::min<int64_t>(dg, 0xFFFF);
+        rowl[(size_t)s * R + l] = (uint64_t)v | ((uint64_t)std::min<int64_t>(dg, 8191) << 19) | ((uint64_t)c->h_row_ptr[v] << 32); // n <= 2^19, nnz < 2^32 in this layout
     }
     std::vector<uint32_t> colt(nnz);
     std::vector<uint64_t> pair((size_t)T * T, 0);
@@ -472,6 +477,8 @@ int ensure_team(fora_ctx *c) {
     HIPCHK(c, hipMalloc(&c->d_team_n2l, n * 4));
     HIPCHK(c, hipMalloc(&c->d_team_l2n, l2n.size() * 4));
     HIPCHK(c, hipMalloc(&c->d_team_deg16, deg16.size() * 2));
+    HIPCHK(c, hipMalloc(&c->d_team_rowl, rowl.size() * 8));
+    HIPCHK(c, hipMemcpy(c->d_team_rowl, rowl.data(), rowl.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), nnz * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_n2l, n2l.data(), n * 4, hipMemcpyHostToDevice));
@@ -547,10 +554,12 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            const uint64_t per_team = 2 * c->team_cap * 4 + 2 * (uint64_t)T * (c->team_R + 64) * 8;
+            const uint64_t per_team = 2 * c->team_cap * 4 + 3 * (uint64_t)T * (c->team_R + 64) * 8;
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
             HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64) * 8));
+            HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
+            HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
             HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 5 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
@@ -682,6 +691,7 @@ int check_dev_err(fora_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bucket_overflow = (e & ERR_BUCKET_OVERFLOW) != 0;
+    if (e) c->team_dirty = true;
     if (e) {
         char buf[256];
         snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x%s)", e,
@@ -851,7 +861,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams;
-    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
+    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;
@@ -869,6 +879,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TEAM_R_CAP + 1) * 8)));
         c->team_attr = true;
     }
+    if (c->team_dirty) { HIPCHK(c, hipMemsetAsync(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8, c->stream)); c->team_dirty = false; }
     HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 5 * 16 * 2) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(a.slot_seq, 0xFF, (size_t)nteams * ((size_t)d.nq + 2) * 4, c->stream));
     int h = ev_begin(c, 10);
@@ -1161,7 +1172,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;

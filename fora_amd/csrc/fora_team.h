@@ -88,6 +88,9 @@ struct TeamDev {
     const uint32_t *n2l;           // [n] owner << 15 | local id of a node, TEAM_EMPTY for a node without in-edges
     const uint32_t *l2n;           // [T][R] node of a local id (TEAM_EMPTY: unused id)
     const uint16_t *deg16;         // [T][R] its out-degree, saturating at 0xFFFF (then Dev::deg has it)
+    const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first edge << 32: one load per pop, by LOCAL id
+    uint64_t *rsvl;                // [nteams][T][R] reserve a member's nodes collect during the slot's push, by local id (all zero between slots): with
+                                   // the row word above a pop is ONE round trip of two coalesced loads -- through l2n and the slot's slab it was two dependent ones
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
     uint32_t *msg;                 // [nteams][2][off[T * T]]
     uint64_t *inct;                // [nteams][2][T][R + 64] increment tables: entry e of member s = the increment of its e-th pop of the level
@@ -135,7 +138,10 @@ __device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE 
 #define TSTAMP_FLUSH() do {} while (0)
 #endif
 
-constexpr uint32_t TEAM_HEAVY = 1024; // rows of more edges are relaxed by the whole workgroup, consecutive lanes on consecutive edges
+#ifndef FORA_TEAM_HEAVY
+#define FORA_TEAM_HEAVY 1024
+#endif
+constexpr uint32_t TEAM_HEAVY = FORA_TEAM_HEAVY; // rows of more edges are relaxed by the whole workgroup, consecutive lanes on consecutive edges
 constexpr int TEAM_NHEAVY = 128;
 constexpr int TEAM_MAXGROUPS = 256;   // 64-id groups of a member at most, the spare id's included
 
@@ -203,7 +209,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t w_pref[TEAM_NW][65];                 // per wave: exclusive prefix of the out-degrees of the nodes of its batch
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
-    __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree
+    __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY], h_cstart[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree (written last: 0 = not there yet), first chunk number
+    __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
     __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 128-message segments; bucket (s -> me)
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext;
@@ -226,6 +233,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
     const uint64_t cap_total = a.off[T * T];
     const uint32_t *l2n = a.l2n + (uint64_t)me * R;
+    const uint64_t *rowl = a.rowl + (uint64_t)me * R;
+    uint64_t *rsvl = a.rsvl + ((uint64_t)team * T + me) * R;
     unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
     for (uint32_t l = tid; l <= R; l += TEAM_THREADS) res[l] = 0;
@@ -357,7 +366,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             // it * 1024 + t, i.e. wave w at the 64-id groups it * 16 + w; no global load (out-degrees in registers).
             uint32_t crossmask = 0;
             if (tid < TEAM_MAX) s_fill[tid] = 0;
-            if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; }
+            if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; s_hchunks = 0; s_hnext = 0; s_wdone = 0; }
+            if (tid < TEAM_NHEAVY) h_deg[tid] = 0;
             if (L > 0) {
                 constexpr int SG = 5; // LDS reads in flight together
 #pragma unroll
@@ -432,7 +442,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 }
                 for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
                     const uint32_t v = l2n[l];
+                    const uint64_t rs = rsvl[l];
                     if (v != TEAM_EMPTY) a.residue[slab + v] = res[l];
+                    if (rs) { a.ppr[slab + v] = rs; rsvl[l] = 0; } // the reserve collected by local id -> the slot's slab (zero there so far)
                     res[l] = 0;
                 }
                 if (tid == 0) { // (the same thread that may have handed the spare id over)
@@ -479,22 +491,29 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     ebase = (uint32_t)__shfl((int)ebase, 0);
                     if ((uint32_t)lane < m) {
                         const uint32_t l = list[lane];
-                        const uint32_t v = l == R ? src : l2n[l];
-                        const uint64_t ri = a.rowinfo[v];
-                        const uint64_t rsv_old = a.ppr[slab + v];
+                        const bool spare = l == R; // the source without in-edges: no local tables
+                        const uint64_t rw = spare ? 0ull : rowl[l];
+                        const uint64_t rsv_old = spare ? a.ppr[slab + src] : rsvl[l];
+                        const uint64_t ri = spare ? a.rowinfo[src] : 0ull;
                         const uint64_t rr = res[l];
                         res[l] = 0;                                       // algo.h:984-985
-                        const uint32_t deg = team_deg(a, ri, v);
+                        uint32_t deg = spare ? team_deg(a, ri, src) : (uint32_t)(rw >> 19) & 8191u;
+                        if (!spare && deg == 8191u) deg = a.deg[(uint32_t)rw & 0x7FFFFu]; // a hub: its exact degree
                         uint64_t rsv_add, dang;
                         const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                        if (rsv_add) a.ppr[slab + v] = rsv_old + rsv_add; // algo.h:986-989 (this member owns v)
+                        if (rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else rsvl[l] = rsv_old + rsv_add; } // algo.h:986-989 (this member owns the node)
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
-                        ebeg = (uint32_t)(ri >> 24);
+                        ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
                         cnt = inc ? deg : 0u;
                         if (cnt) tout[ebase + lane] = inc;
-                        if (cnt > TEAM_HEAVY) { // a hub's row: relaxed by the whole workgroup after the waves' own rows
+                        if (cnt > TEAM_HEAVY) { // a hub's row: cut into chunks that the waves take as they run out of rows of their own
                             const uint32_t hi = atomicAdd(&s_nheavy, 1u);
-                            if (hi < (uint32_t)TEAM_NHEAVY) { h_ent[hi] = ebase + lane; h_ebeg[hi] = ebeg; h_deg[hi] = cnt; cnt = 0; }
+                            if (hi < (uint32_t)TEAM_NHEAVY) {
+                                h_ent[hi] = ebase + lane; h_ebeg[hi] = ebeg;
+                                h_cstart[hi] = atomicAdd(&s_hchunks, (cnt + TEAM_CHUNK - 1) / TEAM_CHUNK);
+                                __atomic_store_n(&h_deg[hi], cnt, __ATOMIC_RELEASE); // (LDS, this wave's writes in order: the row is complete when its degree shows)
+                                cnt = 0;
+                            }
                         }
                     }
                     if (npend > 64) { // keep the entries behind the first 64
@@ -551,31 +570,49 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             // the dangling nodes' mass returns to the source within the level (algo.h:993-998): one message to its owner
             my_dang = wave_sum(my_dang);
             if (lane == 0 && my_dang) atomicAdd(&s_dang, (unsigned long long)my_dang);
-            __syncthreads();
-            { // heavy rows: consecutive lanes on consecutive edges, a chunk per wave and trip
-                const uint32_t nh = min(s_nheavy, (uint32_t)TEAM_NHEAVY);
+            { // heavy rows, chunk by chunk, until every wave is through its own rows and no chunk is left: consecutive lanes on
+              // consecutive edges.  (First form: all heavy rows after a barrier -- the waves that had finished early waited there.)
                 TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
-                for (uint32_t h = 0; h < nh; h++) {
-                    const uint32_t eb = h_ebeg[h], dgh = h_deg[h], ent = h_ent[h] << TEAM_LBITS;
-                    for (uint32_t c0 = wid * TEAM_CHUNK; c0 < dgh; c0 += TEAM_NW * TEAM_CHUNK) {
-                        uint32_t word[TEAM_EPT], dst[TEAM_EPT];
-#pragma unroll
-                        for (int k = 0; k < TEAM_EPT; k++) {
-                            const uint32_t e = c0 + k * 64 + lane;
-                            dst[k] = TEAM_EMPTY; word[k] = 0;
-                            if (e < dgh) {
-                                const uint32_t w = a.colt[(uint64_t)eb + e];
-                                dst[k] = w >> TEAM_LBITS;
-                                word[k] = (w & TEAM_LMASK) | ent;
-                            }
-                        }
-                        team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
+                if (lane == 0) atomicAdd(&s_wdone, 1u);
+                for (;;) {
+                    uint32_t k = TEAM_EMPTY, fin = 0;
+                    if (lane == 0) {
+                        const uint32_t nx = __atomic_load_n(&s_hnext, __ATOMIC_RELAXED), tot = __atomic_load_n(&s_hchunks, __ATOMIC_RELAXED);
+                        if (nx < tot) { if (atomicCAS(&s_hnext, nx, nx + 1u) == nx) k = nx; }
+                        else if (__atomic_load_n(&s_wdone, __ATOMIC_RELAXED) == (uint32_t)TEAM_NW && nx >= __atomic_load_n(&s_hchunks, __ATOMIC_RELAXED)) fin = 1;
                     }
+                    k = (uint32_t)__shfl((int)k, 0);
+                    fin = (uint32_t)__shfl((int)fin, 0);
+                    if (fin) break;
+                    if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
+                    uint32_t eb = 0, dgh = 0, ent = 0, c0 = 0;
+                    for (bool found = false; !found;) { // the row of chunk k (it may still be on its way into the list)
+                        const uint32_t nh = min(__atomic_load_n(&s_nheavy, __ATOMIC_RELAXED), (uint32_t)TEAM_NHEAVY);
+                        for (uint32_t h = 0; h < nh; h++) {
+                            const uint32_t dg = __atomic_load_n(&h_deg[h], __ATOMIC_ACQUIRE);
+                            if (!dg) continue;
+                            const uint32_t cs = h_cstart[h];
+                            if (k >= cs && k < cs + (dg + TEAM_CHUNK - 1) / TEAM_CHUNK) { eb = h_ebeg[h]; dgh = dg; ent = h_ent[h] << TEAM_LBITS; c0 = (k - cs) * TEAM_CHUNK; found = true; break; }
+                        }
+                    }
+                    uint32_t word[TEAM_EPT], dst[TEAM_EPT];
+#pragma unroll
+                    for (int kk = 0; kk < TEAM_EPT; kk++) {
+                        const uint32_t e = c0 + kk * 64 + lane;
+                        dst[kk] = TEAM_EMPTY; word[kk] = 0;
+                        if (e < dgh) {
+                            const uint32_t w = a.colt[(uint64_t)eb + e];
+                            dst[kk] = w >> TEAM_LBITS;
+                            word[kk] = (w & TEAM_LMASK) | ent;
+                        }
+                    }
+                    team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
                 }
             }
+            TSTAMP(6);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave's message stores have completed before the barrier
             __syncthreads();
-            TSTAMP(4);
+            TSTAMP(7);
             if (tid == 0 && s_dang) { // one more table entry, one more message
                 const uint32_t ent = s_ncross, pos = s_fill[src_owner];
                 tout[ent] = s_dang;
