@@ -61,6 +61,7 @@ struct Tunables {
     int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
     int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
+    int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -70,7 +71,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -120,6 +121,8 @@ struct fora_ctx {
     WalkDG dg{};
     // team push (fora_team.h): target copy of col, bucket offsets; built by set_graph for graphs of the narrow layout
     uint32_t *d_colt = nullptr, *d_team_off = nullptr, *d_team_n2l = nullptr, *d_team_l2n = nullptr;
+    uint32_t *d_team_hubtgt = nullptr;
+    uint32_t team_H = 0, team_hubs_opt = 0;
     uint64_t *d_team_rowl = nullptr, *d_team_rsvl = nullptr; // rows by local id (graph); reserve accumulators by local id (workspace)
     uint16_t *d_team_deg16 = nullptr;
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
@@ -242,7 +245,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt); c->team_H = 0; c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -417,9 +420,11 @@ int ensure_team(fora_ctx *c) {
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
     const bool want = want_team(c);
     const uint32_t force = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_size, 0), TEAM_MAX);
-    if (c->team_checked && want == c->team_wanted && (!want || c->team_force == force)) return FORA_OK;
+    const uint32_t hubs_opt = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_hubs, 0), 4096);
+    if (c->team_checked && want == c->team_wanted && (!want || (c->team_force == force && c->team_hubs_opt == hubs_opt))) return FORA_OK;
     c->team_checked = true; c->team_wanted = want;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl);
+    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt);
+    c->team_H = 0; c->team_hubs_opt = hubs_opt;
     c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_force = force;
     if (!want) return FORA_OK;
     const size_t n = (size_t)c->n, nnz = (size_t)c->nnz;
@@ -453,16 +458,31 @@ int ensure_team(fora_ctx *c) {
         deg16[(size_t)s * R + l] = (uint16_t)std::min<int64_t>(dg, 0xFFFF);
         rowl[(size_t)s * R + l] = (uint64_t)v | ((uint64_t)std::min<int64_t>(dg, 8191) << 19) | ((uint64_t)c->h_row_ptr[v] << 32); // n <= 2^19, nnz < 2^32 in this layout
     }
+    // hubs: the nodes of largest in-degree (ties: lower id); their sums travel as one message per member and level
+    // (their LDS sums share the 160 KiB with the residues and ~23 KB of static arrays)
+    const uint64_t lds_left = 163840 / TEAM_WGS_PER_CU - 23 * 1024 - ((uint64_t)R + 1) * 8;
+    const uint32_t Hn = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(hubs_opt, n), lds_left / 8);
+    std::vector<uint32_t> hub_of(n, TEAM_EMPTY), hubtgt(std::max<uint32_t>(1, Hn), 0);
+    std::vector<uint8_t> hub_ok(std::max<uint32_t>(1, Hn), 0);
+    if (Hn) {
+        std::vector<uint32_t> order(n);
+        for (size_t v = 0; v < n; v++) order[v] = (uint32_t)v;
+        std::partial_sort(order.begin(), order.begin() + Hn, order.end(),
+                          [&](uint32_t x, uint32_t y) { return indeg[x] != indeg[y] ? indeg[x] > indeg[y] : x < y; });
+        for (uint32_t h = 0; h < Hn; h++) if (indeg[order[h]]) { hub_of[order[h]] = h; hubtgt[h] = n2l[order[h]]; hub_ok[h] = 1; }
+    }
     std::vector<uint32_t> colt(nnz);
     std::vector<uint64_t> pair((size_t)T * T, 0);
     for (size_t v = 0; v < n; v++) {
         const uint32_t s = (uint32_t)((v >> 6) % T);
         for (int64_t e = c->h_row_ptr[v]; e < c->h_row_ptr[v + 1]; e++) {
-            const uint32_t w = n2l[(size_t)col[(size_t)e]];
-            colt[(size_t)e] = w;
-            pair[(size_t)s * T + (w >> TEAM_LBITS)]++;
+            const uint32_t t = (uint32_t)col[(size_t)e], w = n2l[t];
+            colt[(size_t)e] = hub_of[t] != TEAM_EMPTY ? (0x80000000u | hub_of[t]) : w;
+            if (hub_of[t] == TEAM_EMPTY) pair[(size_t)s * T + (w >> TEAM_LBITS)]++;
         }
     }
+    for (uint32_t h = 0; h < Hn; h++) // a member sends a hub at most one message per level
+        if (hub_ok[h]) for (uint32_t s = 0; s < T; s++) pair[(size_t)s * T + (hubtgt[h] >> TEAM_LBITS)]++;
     // bucket (s -> d): one 4-byte message per edge + the dangling mass of the level; whole 64-byte lines
     std::vector<uint32_t> off((size_t)T * T + 1, 0);
     uint64_t at = 0;
@@ -477,6 +497,9 @@ int ensure_team(fora_ctx *c) {
     HIPCHK(c, hipMalloc(&c->d_team_n2l, n * 4));
     HIPCHK(c, hipMalloc(&c->d_team_l2n, l2n.size() * 4));
     HIPCHK(c, hipMalloc(&c->d_team_deg16, deg16.size() * 2));
+    HIPCHK(c, hipMalloc(&c->d_team_hubtgt, hubtgt.size() * 4));
+    HIPCHK(c, hipMemcpy(c->d_team_hubtgt, hubtgt.data(), hubtgt.size() * 4, hipMemcpyHostToDevice));
+    c->team_H = Hn;
     HIPCHK(c, hipMalloc(&c->d_team_rowl, rowl.size() * 8));
     HIPCHK(c, hipMemcpy(c->d_team_rowl, rowl.data(), rowl.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), nnz * 4, hipMemcpyHostToDevice));
@@ -554,10 +577,10 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            const uint64_t per_team = 2 * c->team_cap * 4 + 3 * (uint64_t)T * (c->team_R + 64) * 8;
+            const uint64_t per_team = 2 * c->team_cap * 4 + 3 * (uint64_t)T * (c->team_R + 64 + c->team_H) * 8;
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
             HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
-            HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64) * 8));
+            HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
@@ -861,7 +884,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams;
-    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
+    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;
@@ -874,9 +897,11 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.xcd = (c->opt_.team_xcd >= 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? (uint32_t)c->opt_.team_xcd : 0u;
     a.stamps = c->d_stamps;
     a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
-    const size_t lds = ((size_t)a.R + 1) * 8;
-    if (!c->team_attr) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TEAM_R_CAP + 1) * 8)));
+    const size_t lds = ((size_t)a.R + 1 + a.H) * 8;
+    if (!c->team_attr) { // dynamic LDS up to what the static arrays leave of the CU's 160 KiB
+        hipFuncAttributes fa{};
+        HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)k_push_team));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(163840 - (int)fa.sharedSizeBytes)));
         c->team_attr = true;
     }
     if (c->team_dirty) { HIPCHK(c, hipMemsetAsync(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8, c->stream)); c->team_dirty = false; }
@@ -1172,7 +1197,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
+    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->d_team_hubtgt = c->d_team_hubtgt; w->team_H = c->team_H; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;

@@ -91,9 +91,14 @@ struct TeamDev {
     const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first edge << 32: one load per pop, by LOCAL id
     uint64_t *rsvl;                // [nteams][T][R] reserve a member's nodes collect during the slot's push, by local id (all zero between slots): with
                                    // the row word above a pop is ONE round trip of two coalesced loads -- through l2n and the slot's slab it was two dependent ones
+    // Hub pre-aggregation: an edge whose target is one of the H nodes of largest in-degree (colt word 0x80000000 | hub) adds
+    // its increment to the member's LDS sum of that hub; after the level's rows every non-zero sum leaves as ONE message
+    // (its own entry of the increment table).  On the ws-sized graph 27 % of all edges end at the top 1024 nodes.
+    uint32_t H;                    // hubs (0: none)
+    const uint32_t *hubtgt;        // [H] owner << 15 | local id of hub h
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
     uint32_t *msg;                 // [nteams][2][off[T * T]]
-    uint64_t *inct;                // [nteams][2][T][R + 64] increment tables: entry e of member s = the increment of its e-th pop of the level
+    uint64_t *inct;                // [nteams][2][T][R + 64 + H] increment tables: entry e of member s = the increment of its e-th pop of the level; behind the pops: the dangling mass, then the hub sums
     uint32_t *cnt;                 // [nteams][2][T * T] messages in bucket (s -> d) this level
     unsigned long long *sync;      // [nteams][5][16] barrier words, one 128-byte line each; the fifth: the members' XCD census
     uint32_t *slot_seq;            // [nteams][nq + 2] slot taken by the team in its k-th turn (TEAM_EMPTY: not yet)
@@ -204,12 +209,15 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
 // level's 64-id groups from a shared counter, collect the crossing nodes in a wave-private list and pop / emit them 64 at a
 // time on their own (prefix sums by wave scan), so the sixteen waves of a member overlap each other's memory round trips.
 __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev a) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
-    extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id
+    extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id; then [H] hub sums of the level
     __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
     __shared__ uint32_t w_pref[TEAM_NW][65];                 // per wave: exclusive prefix of the out-degrees of the nodes of its batch
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
     __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY], h_cstart[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree (written last: 0 = not there yet), first chunk number
+    __shared__ uint64_t w_inc[TEAM_NW][64];                  // per wave: increments of the nodes of its batch (hub edges add them in LDS)
+    __shared__ uint64_t h_inc[TEAM_NHEAVY];
+    __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
     __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 128-message segments; bucket (s -> me)
@@ -217,7 +225,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ unsigned long long s_dang, s_acc[3];
 
     const uint32_t T = a.T, R = a.R;
-    const uint32_t tstride = R + 64; // entries of one increment table
+    const uint32_t H = a.H;
+    const uint32_t tstride = R + 64 + H; // entries of one increment table
+    unsigned long long *s_hub = (unsigned long long *)(res + R + 1); // [H]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t team, me;
@@ -237,7 +247,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     uint64_t *rsvl = a.rsvl + ((uint64_t)team * T + me) * R;
     unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
-    for (uint32_t l = tid; l <= R; l += TEAM_THREADS) res[l] = 0;
+    for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
     if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
     uint32_t dgp[(TEAM_NIT + 1) / 2];
@@ -366,7 +376,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             // it * 1024 + t, i.e. wave w at the 64-id groups it * 16 + w; no global load (out-degrees in registers).
             uint32_t crossmask = 0;
             if (tid < TEAM_MAX) s_fill[tid] = 0;
-            if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; s_hchunks = 0; s_hnext = 0; s_wdone = 0; }
+            if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; s_hchunks = 0; s_hnext = 0; s_wdone = 0; s_hubent = 0; }
             if (tid < TEAM_NHEAVY) h_deg[tid] = 0;
             if (L > 0) {
                 constexpr int SG = 5; // LDS reads in flight together
@@ -463,6 +473,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             {
                 uint16_t *list = w_list[wid];
                 uint32_t *pref = w_pref[wid];
+                uint64_t *winc = w_inc[wid];
                 TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
                 uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
@@ -506,10 +517,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
                         cnt = inc ? deg : 0u;
                         if (cnt) tout[ebase + lane] = inc;
+                        winc[lane] = inc;
                         if (cnt > TEAM_HEAVY) { // a hub's row: cut into chunks that the waves take as they run out of rows of their own
                             const uint32_t hi = atomicAdd(&s_nheavy, 1u);
                             if (hi < (uint32_t)TEAM_NHEAVY) {
-                                h_ent[hi] = ebase + lane; h_ebeg[hi] = ebeg;
+                                h_ent[hi] = ebase + lane; h_ebeg[hi] = ebeg; h_inc[hi] = inc;
                                 h_cstart[hi] = atomicAdd(&s_hchunks, (cnt + TEAM_CHUNK - 1) / TEAM_CHUNK);
                                 __atomic_store_n(&h_deg[hi], cnt, __ATOMIC_RELEASE); // (LDS, this wave's writes in order: the row is complete when its degree shows)
                                 cnt = 0;
@@ -560,6 +572,10 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         for (int k = 0; k < TEAM_EPT; k++) {
                             dst[k] = w[k] == TEAM_EMPTY ? TEAM_EMPTY : w[k] >> TEAM_LBITS;
                             word[k] = (w[k] & TEAM_LMASK) | ((ebase + si[k]) << TEAM_LBITS);
+                            if (w[k] != TEAM_EMPTY && (w[k] & 0x80000000u)) { // a hub: summed here
+                                atomicAdd(&s_hub[w[k] & 0x7FFFFFFFu], (unsigned long long)winc[si[k]]);
+                                dst[k] = TEAM_EMPTY;
+                            }
                         }
                         team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
                     }
@@ -586,13 +602,14 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     if (fin) break;
                     if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
                     uint32_t eb = 0, dgh = 0, ent = 0, c0 = 0;
+                    uint64_t hinc = 0;
                     for (bool found = false; !found;) { // the row of chunk k (it may still be on its way into the list)
                         const uint32_t nh = min(__atomic_load_n(&s_nheavy, __ATOMIC_RELAXED), (uint32_t)TEAM_NHEAVY);
                         for (uint32_t h = 0; h < nh; h++) {
                             const uint32_t dg = __atomic_load_n(&h_deg[h], __ATOMIC_ACQUIRE);
                             if (!dg) continue;
                             const uint32_t cs = h_cstart[h];
-                            if (k >= cs && k < cs + (dg + TEAM_CHUNK - 1) / TEAM_CHUNK) { eb = h_ebeg[h]; dgh = dg; ent = h_ent[h] << TEAM_LBITS; c0 = (k - cs) * TEAM_CHUNK; found = true; break; }
+                            if (k >= cs && k < cs + (dg + TEAM_CHUNK - 1) / TEAM_CHUNK) { eb = h_ebeg[h]; dgh = dg; ent = h_ent[h] << TEAM_LBITS; hinc = h_inc[h]; c0 = (k - cs) * TEAM_CHUNK; found = true; break; }
                         }
                     }
                     uint32_t word[TEAM_EPT], dst[TEAM_EPT];
@@ -602,8 +619,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         dst[kk] = TEAM_EMPTY; word[kk] = 0;
                         if (e < dgh) {
                             const uint32_t w = a.colt[(uint64_t)eb + e];
-                            dst[kk] = w >> TEAM_LBITS;
-                            word[kk] = (w & TEAM_LMASK) | ent;
+                            if (w & 0x80000000u) atomicAdd(&s_hub[w & 0x7FFFFFFFu], (unsigned long long)hinc);
+                            else { dst[kk] = w >> TEAM_LBITS; word[kk] = (w & TEAM_LMASK) | ent; }
                         }
                     }
                     team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
@@ -614,10 +631,18 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             __syncthreads();
             TSTAMP(7);
             if (tid == 0 && s_dang) { // one more table entry, one more message
-                const uint32_t ent = s_ncross, pos = s_fill[src_owner];
+                const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
                 tout[ent] = s_dang;
                 mout[s_moff[src_owner] + pos] = src_local | (ent << TEAM_LBITS);
-                s_fill[src_owner] = pos + 1;
+            }
+            for (uint32_t h = tid; h < H; h += TEAM_THREADS) { // the hubs' sums of this level: one message each
+                const unsigned long long hv = s_hub[h];
+                if (hv) {
+                    s_hub[h] = 0;
+                    const uint32_t tg = a.hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
+                    tout[ent] = hv;
+                    mout[s_moff[tg >> TEAM_LBITS] + atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
+                }
             }
             __syncthreads();
             if ((uint32_t)tid < T) (a.cnt + ((uint64_t)team * 2 + (g & 1u)) * T * T)[me * T + tid] = s_fill[tid];
