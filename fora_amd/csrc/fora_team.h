@@ -314,6 +314,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         uint32_t peak = 0, nlev = 0;
         bool final_round = false;
 
+#ifdef FORA_STAMPS_LEVELS
+        long long lv_t_ = clock64();
+#endif
         for (uint32_t L = 0;; L++) {
             // ================= consume: the messages of the previous level that are addressed to me
             if (L > 0) {
@@ -668,6 +671,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             }
             __syncthreads();
             TSTAMP(5);
+#ifdef FORA_STAMPS_LEVELS
+            if (tid == 0) { const long long n_ = clock64(); atomicAdd(&a.stamps[L < 31 ? L : 31], (unsigned long long)(n_ - lv_t_)); lv_t_ = n_; }
+#endif
             if (!s_ok) return;
             g++;
             const uint32_t F = s_F; // nodes the team popped in this level

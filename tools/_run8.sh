@@ -1,3 +1,16 @@
-timeout 900 python3 -m pytest tests/test_hip_parity_gpu.py tests/test_edge_cases_gpu.py -x -q -m gpu -k "team or query_bit or push_bit or random_small" 2>&1 | tail -2
-echo "== stamps hubs 1024"; python3 tools/pushbench.py --reps 3 variants/lib_stamps.so | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('tail_ms','team_ms','push_ms','stamps_bin_Mcyc')})"
-for h in 0 256 512 2048; do echo "== hubs $h"; FORA_HIP_TEAM_HUBS=$h python3 tools/pushbench.py --reps 3 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('tail_ms','team_ms','push_ms')})"; done
+python3 - <<'PY'
+import os, sys, json
+os.environ["FORA_HIP_LIB"] = os.path.abspath("variants/lib_levels.so")
+sys.path.insert(0, ".")
+import numpy as np, fora_amd
+from fora_amd import synth
+n, m, row_ptr, col = synth.preset("webstanford")
+eng = fora_amd.Engine(0); eng.set_graph(n, m, row_ptr, col); eng.set_params(alpha=0.2, epsilon=0.5, seed=1)
+srcs = synth.query_set(n, 1000, 20261001)
+eng.push(srcs, want=False)
+st0 = eng.stamps().astype(np.int64)
+eng.push(srcs, want=False)
+st = eng.stamps().astype(np.int64) - st0
+print("Mcyc per level (sum over 256 WGs):", [round(int(x) / 1e6) for x in st])
+print("total", round(st.sum() / 1e6))
+PY
