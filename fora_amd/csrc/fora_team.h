@@ -211,10 +211,10 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
 __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev a) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
     extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id; then [H] hub sums of the level
     __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
-    __shared__ uint32_t w_pref[TEAM_NW][65];                 // per wave: exclusive prefix of the out-degrees of the nodes of its batch
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
     __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY], h_cstart[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree (written last: 0 = not there yet), first chunk number
+    __shared__ uint8_t w_mark[TEAM_NW][TEAM_CHUNK] __attribute__((aligned(4))); // per wave: row marks of a chunk's edges
     __shared__ uint64_t w_inc[TEAM_NW][64];                  // per wave: increments of the nodes of its batch (hub edges add them in LDS)
     __shared__ uint64_t h_inc[TEAM_NHEAVY];
     __shared__ uint32_t s_hubent;
@@ -475,8 +475,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             uint64_t my_dang = 0;
             {
                 uint16_t *list = w_list[wid];
-                uint32_t *pref = w_pref[wid];
                 uint64_t *winc = w_inc[wid];
+                uint8_t *mark = w_mark[wid];
                 TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
                 uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
@@ -539,36 +539,46 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     npend -= m;
                     uint32_t total;
                     const uint32_t pre = wave_excl_scan(cnt, total);
-                    pref[lane] = pre;
-                    if (lane == 0) pref[64] = total;
                     TSTAMP(2);
-                    // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows
+                    // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows.  Which row an edge
+                    // belongs to comes from MARKS: every row with edges writes its number at the stage position of its first edge,
+                    // a lane reads the marks of its edges in one word, and a wave scan ("the last mark so far") fills the gaps --
+                    // about a third of the instructions of the binary search + stepping it replaces (the chunk loop is bound by
+                    // its instruction count: 1.2 per edge at 1.16 CU-cycles per edge).
+                    static_assert(TEAM_EPT == 4, "a lane's marks are one 32-bit word");
+                    const uint32_t rowbase = ebeg - pre; // colt index of edge e of this lane's row: rowbase + e (mod 2^32)
+                    uint32_t carry = 0;                  // row (+ 1) of the last edge of the chunks before
                     for (uint32_t cb = 0; cb < total; cb += TEAM_CHUNK) {
-                        const uint32_t e0 = cb + lane * TEAM_EPT;
-                        uint32_t lo = 0;
-                        if (e0 < total) {
-                            uint32_t hi = 64;
+                        ((uint32_t *)mark)[lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (cnt && pre - cb < (uint32_t)TEAM_CHUNK) mark[pre - cb] = (uint8_t)(lane + 1); // (pre >= cb: rows before were marked in their chunk)
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t mk4 = ((const uint32_t *)mark)[lane];
+                        const uint32_t m0 = mk4 & 255u, m1 = (mk4 >> 8) & 255u, m2 = (mk4 >> 16) & 255u, m3 = mk4 >> 24;
+                        uint32_t x = m3 ? m3 : m2 ? m2 : m1 ? m1 : m0; // inclusive scan: the last mark at or before this lane
 #pragma unroll
-                            for (int s6 = 0; s6 < 6; s6++) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (pref[mid] <= e0) lo = mid; else hi = mid;
-                            }
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+                            if (lane >= o && !x) x = y;
                         }
+                        const uint32_t below = (uint32_t)__shfl_up((int)x, 1);
+                        const uint32_t inh = (lane && below) ? below : carry; // the last mark before this lane's edges
+                        const uint32_t lastx = (uint32_t)__shfl((int)x, 63);
+                        if (lastx) carry = lastx;
                         uint32_t si[TEAM_EPT];
-#pragma unroll
-                        for (int k = 0; k < TEAM_EPT; k++) {
-                            const uint32_t e = e0 + k;
-                            if (e < total) while (pref[lo + 1] <= e) lo++; // entries without edges
-                            si[k] = lo;
-                        }
+                        si[0] = (m0 ? m0 : inh);
+                        si[1] = (m1 ? m1 : si[0]);
+                        si[2] = (m2 ? m2 : si[1]);
+                        si[3] = (m3 ? m3 : si[2]);
+                        const uint32_t e0 = cb + lane * TEAM_EPT;
                         uint32_t w[TEAM_EPT];
 #pragma unroll
-                        for (int k = 0; k < TEAM_EPT; k++) { // (every lane takes part in the exchanges)
+                        for (int k = 0; k < TEAM_EPT; k++) { // (every lane takes part in the exchanges; loads without a branch around them)
                             const uint32_t e = e0 + k;
-                            const uint32_t eb = (uint32_t)__shfl((int)ebeg, (int)si[k]);
-                            const uint32_t pb = (uint32_t)__shfl((int)pre, (int)si[k]);
-                            w[k] = TEAM_EMPTY;
-                            if (e < total) w[k] = a.colt[(uint64_t)eb + (e - pb)];
+                            si[k] = si[k] ? si[k] - 1u : 0u;
+                            const uint32_t rb = (uint32_t)__shfl((int)rowbase, (int)si[k]);
+                            const uint32_t wv = a.colt[e < total ? rb + e : 0u];
+                            w[k] = e < total ? wv : TEAM_EMPTY;
                         }
                         uint32_t word[TEAM_EPT], dst[TEAM_EPT];
 #pragma unroll
