@@ -389,15 +389,27 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Cross-lane moves on the VALU (DPP, gfx9 controls): row_shr:n = 0x110 + n shifts inside a row of 16 lanes, row_bcast:15 /
+// row_bcast:31 (0x142 / 0x143) hand the last lane of a row / of the lower half to the lanes above, wave_shr:1 (0x138) shifts
+// the whole wave by one.  Lanes without a source (and rows outside ROWS) read 0.  A wave scan is six of these instead of six
+// LDS round trips (ds_bpermute).
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, false); }
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t x) {
+    x += dpp0<0x111>(x); x += dpp0<0x112>(x); x += dpp0<0x114>(x); x += dpp0<0x118>(x);
+    x += dpp0<0x142, 0xA>(x);
+    x += dpp0<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t x) {
+    x = max(x, dpp0<0x111>(x)); x = max(x, dpp0<0x112>(x)); x = max(x, dpp0<0x114>(x)); x = max(x, dpp0<0x118>(x));
+    x = max(x, dpp0<0x142, 0xA>(x));
+    x = max(x, dpp0<0x143, 0xC>(x));
+    return x;
+}
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
-    const int lane = threadIdx.x & 63;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
-    total = __shfl(x, 63);
+    const uint32_t x = wave_incl_scan_add(v);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 // exclusive scan over the NT threads of a block; s_w: NT / 64-entry LDS scratch

@@ -163,9 +163,15 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
                                           uint32_t *s_fill, const uint32_t *s_moff, uint32_t *mout, uint32_t T, int lane) {
 #if !FORA_TEAM_STAGE
     // direct form: every message takes its place from the workgroup's fill counter and is stored on its own
+    uint32_t rk[TEAM_EPT], first[TEAM_EPT]; // (all four counter round trips in flight together, then the stores)
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++) {
+        rk[k] = 0; first[k] = 0;
+        if (dst[k] != TEAM_EMPTY) { rk[k] = atomicAdd(&s_fill[dst[k]], 1u); first[k] = s_moff[dst[k]]; }
+    }
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++)
-        if (dst[k] != TEAM_EMPTY) mout[s_moff[dst[k]] + atomicAdd(&s_fill[dst[k]], 1u)] = word[k];
+        if (dst[k] != TEAM_EMPTY) mout[first[k] + rk[k]] = word[k];
     return;
 #endif
     if (lane < TEAM_MAX) st.hist[lane] = 0;
@@ -220,7 +226,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
-    __shared__ uint32_t s_cpre[TEAM_MAX + 1], s_cseg[TEAM_MAX + 1], s_coff[TEAM_MAX]; // messages waiting for me per source: prefix of counts, of 128-message segments; bucket (s -> me)
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext;
     __shared__ unsigned long long s_dang, s_acc[3];
 
@@ -248,7 +253,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
     for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
-    if (tid < (int)T) { s_moff[tid] = a.off[me * T + tid]; s_coff[tid] = a.off[tid * T + me]; }
+    if (tid < (int)T) s_moff[tid] = a.off[me * T + tid];
+    const uint32_t coffv = (uint32_t)lane < T ? a.off[(uint32_t)lane * T + me] : 0u; // first slot of bucket (lane -> me)
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
     uint32_t dgp[(TEAM_NIT + 1) / 2];
 #pragma unroll
@@ -323,38 +329,33 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const uint32_t *cin = a.cnt + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * T;
                 const uint32_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
                 const uint64_t *tin = a.inct + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * tstride;
-                if (tid < 64) {
-                    const uint32_t c = (uint32_t)lane < T ? __hip_atomic_load(&cin[(uint32_t)lane * T + me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; // (sc1: past L1, like every load of handed-over data)
-                    uint32_t tot, tots;
-                    const uint32_t ex = wave_excl_scan(c, tot);
-                    const uint32_t exs = wave_excl_scan((c + 127u) >> 7, tots);
-                    if ((uint32_t)lane < T) { s_cpre[lane] = ex; s_cseg[lane] = exs; }
-                    if (lane == 0) { s_cpre[T] = tot; s_cseg[T] = tots; }
-                }
-                __syncthreads();
-                // a wave takes 128-message segments wid, wid + 16, ... (two messages per lane), CU of them per trip: all
-                // message loads in flight together, then all increment gathers
-                const uint32_t nseg = s_cseg[T];
+                // Every wave reads the T counts itself (lane s: the messages source s has for me) and takes the 128-message
+                // segments j of source s with (j + s) % 16 == its number: balanced whether the buckets are long (peak levels)
+                // or hold one segment each, and which (source, segment) its i-th one is follows from a scan of the per-source
+                // counts and a ballot -- no table in LDS, no workgroup barrier before the first message load.  CU segments per
+                // trip: all message loads in flight together (two messages per lane), then all increment gathers.
+                const uint32_t c = (uint32_t)lane < T ? __hip_atomic_load(&cin[(uint32_t)lane * T + me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; // (sc1: past L1, like every load of handed-over data)
+                const uint32_t ns = (c + 127u) >> 7;
+                const uint32_t r0 = ((uint32_t)wid + 2u * TEAM_NW - (uint32_t)lane % TEAM_NW) % TEAM_NW; // my first segment of source `lane`
+                const uint32_t kmine = ns > r0 ? (ns - r0 + TEAM_NW - 1) / TEAM_NW : 0u;
+                uint32_t nmine;
+                const uint32_t pmine = wave_excl_scan(kmine, nmine);
                 constexpr int CU = FORA_TEAM_CU;
-                for (uint32_t j0 = wid; j0 < nseg; j0 += TEAM_NW * CU) {
+                for (uint32_t i0 = 0; i0 < nmine; i0 += CU) {
                     uint2 m[CU];
                     uint32_t srcm[CU], left[CU];
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
-                        const uint32_t j = j0 + k * TEAM_NW;
-                        const uint32_t jc = j < nseg ? j : 0u;
-                        uint32_t lo = 0, hi = T; // largest lo with s_cseg[lo] <= jc (wave-uniform)
-#pragma unroll
-                        for (int it = 0; it < 5; it++) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (hi - lo > 1) { if (s_cseg[mid] <= jc) lo = mid; else hi = mid; }
-                        }
-                        const uint32_t idx = ((jc - s_cseg[lo]) << 7) + 2u * lane;
-                        const uint32_t n_s = s_cpre[lo + 1] - s_cpre[lo];
-                        left[k] = (j < nseg && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
-                        srcm[k] = lo;
+                        const bool have = i0 + k < nmine;              // (wave-uniform)
+                        const uint32_t ic = have ? i0 + k : 0u;
+                        const uint32_t sidx = (uint32_t)__popcll(__ballot(pmine <= ic)) - 1u; // the last source whose segments start at or before my ic-th (lanes >= T: pmine = nmine > ic)
+                        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)r0, (int)sidx) + (ic - (uint32_t)__builtin_amdgcn_readlane((int)pmine, (int)sidx)) * TEAM_NW;
+                        const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)sidx);
+                        const uint32_t idx = (j << 7) + 2u * lane;
+                        left[k] = (have && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
+                        srcm[k] = sidx;
                         {
-                            const unsigned long long mm = __hip_atomic_load((const unsigned long long *)(min_ + (uint64_t)s_coff[lo] + (left[k] ? idx : 0u)),
+                            const unsigned long long mm = __hip_atomic_load((const unsigned long long *)(min_ + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)coffv, (int)sidx) + (left[k] ? idx : 0u)),
                                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (buckets hold a multiple of 16 words)
                             m[k].x = (uint32_t)mm; m[k].y = (uint32_t)(mm >> 32);
                         }
@@ -555,15 +556,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t mk4 = ((const uint32_t *)mark)[lane];
                         const uint32_t m0 = mk4 & 255u, m1 = (mk4 >> 8) & 255u, m2 = (mk4 >> 16) & 255u, m3 = mk4 >> 24;
-                        uint32_t x = m3 ? m3 : m2 ? m2 : m1 ? m1 : m0; // inclusive scan: the last mark at or before this lane
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-                            if (lane >= o && !x) x = y;
-                        }
-                        const uint32_t below = (uint32_t)__shfl_up((int)x, 1);
-                        const uint32_t inh = (lane && below) ? below : carry; // the last mark before this lane's edges
-                        const uint32_t lastx = (uint32_t)__shfl((int)x, 63);
+                        // (marks grow with the lane: "the last mark so far" is a prefix maximum)
+                        const uint32_t x = wave_incl_scan_max(m3 ? m3 : m2 ? m2 : m1 ? m1 : m0);
+                        const uint32_t below = dpp0<0x138>(x);                 // lane - 1's (lane 0: none)
+                        const uint32_t inh = below ? below : carry;            // the last mark before this lane's edges
+                        const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
                         if (lastx) carry = lastx;
                         uint32_t si[TEAM_EPT];
                         si[0] = (m0 ? m0 : inh);
@@ -577,9 +574,12 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             const uint32_t e = e0 + k;
                             si[k] = si[k] ? si[k] - 1u : 0u;
                             const uint32_t rb = (uint32_t)__shfl((int)rowbase, (int)si[k]);
-                            const uint32_t wv = a.colt[e < total ? rb + e : 0u];
-                            w[k] = e < total ? wv : TEAM_EMPTY;
+                            w[k] = a.colt[e < total ? rb + e : 0u];
                         }
+                        __builtin_amdgcn_sched_barrier(0); // all four loads are on their way before the first is waited for
+#pragma unroll
+                        for (int k = 0; k < TEAM_EPT; k++)
+                            if (e0 + k >= total) w[k] = TEAM_EMPTY;
                         uint32_t word[TEAM_EPT], dst[TEAM_EPT];
 #pragma unroll
                         for (int k = 0; k < TEAM_EPT; k++) {
