@@ -989,9 +989,12 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
 #ifndef FORA_TAIL_EPT
 #define FORA_TAIL_EPT 4
 #endif
+#ifndef FORA_TAIL_WPE
+#define FORA_TAIL_WPE 4
+#endif
 constexpr int TAIL_THREADS = FORA_TAIL_THREADS;
 constexpr int TAIL_EPT = FORA_TAIL_EPT; // relaxations a lane keeps in flight
-__global__ void __launch_bounds__(TAIL_THREADS) k_push_tail(Dev d, int L0, int max_levels) {
+__global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d, int L0, int max_levels) {
     __shared__ int64_t s_ebeg[TAIL_THREADS];
     __shared__ uint64_t s_inc[TAIL_THREADS];
     __shared__ uint32_t s_pref[TAIL_THREADS + 1];

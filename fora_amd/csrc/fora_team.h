@@ -245,6 +245,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         me = blockIdx.x % T;
     }
     const uint32_t nit = (R + TEAM_THREADS - 1) / TEAM_THREADS; // <= TEAM_NIT
+    const bool thr_small = (a.t1 >> 47) == 0;                    // then a 16-bit degree's threshold is two multiplies (see the sweep)
+    const uint32_t t1_lo = (uint32_t)a.t1, t1_hi = (uint32_t)(a.t1 >> 32);
     const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
     const uint64_t cap_total = a.off[T * T];
     const uint32_t *l2n = a.l2n + (uint64_t)me * R;
@@ -400,8 +402,14 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                 bool c = false;
                                 if (r[k]) {
                                     uint32_t dg = (dgp[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu;
-                                    if (dg == 0xFFFFu) dg = a.deg[l2n[it * TEAM_THREADS + tid]]; // a hub: its exact degree
-                                    c = r[k] >= node_thr(a.t1, dg);
+                                    asm volatile("" : "+v"(dg)); // (or the compiler keeps fifteen 64-bit thresholds per thread across the levels -- and spills them)
+                                    if (dg == 0xFFFFu) { // a hub: its exact degree
+                                        uint32_t li = it * TEAM_THREADS + tid;
+                                        asm volatile("" : "+v"(li)); // (keeps the fifteen addresses of this rare path out of the level loop's registers)
+                                        c = r[k] >= node_thr(a.t1, a.deg[l2n[li]]);
+                                    }
+                                    else if (thr_small) c = r[k] >= (uint64_t)t1_lo * dg + ((uint64_t)(t1_hi * dg) << 32); // t1 < 2^47, dg < 2^16: no overflow (dg 0: any residue crosses)
+                                    else c = r[k] >= node_thr(a.t1, dg);
                                 }
                                 if (c) crossmask |= 1u << it;
                                 const unsigned long long mk = __ballot(c);
@@ -640,8 +648,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 }
             }
             TSTAMP(6);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave's message stores have completed before the barrier
-            __syncthreads();
+            __syncthreads(); // (the message stores are waited for below, together with the counts)
             TSTAMP(7);
             if (tid == 0 && s_dang) { // one more table entry, one more message
                 const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
@@ -659,7 +666,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             }
             __syncthreads();
             if ((uint32_t)tid < T) (a.cnt + ((uint64_t)team * 2 + (g & 1u)) * T * T)[me * T + tid] = s_fill[tid];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message, table and count stores have completed
             __syncthreads();
             // ================= the team's barrier; the level's frontier size comes with it
             if (tid == 0) {
