@@ -132,7 +132,8 @@ struct fora_ctx {
     // ... and its workspace
     uint32_t *d_team_msg = nullptr;
     uint64_t *d_team_inct = nullptr;
-    uint32_t *d_team_cnt = nullptr, *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
+    unsigned long long *d_team_cnt = nullptr; // the teams' barrier words (TeamDev::cntw)
+    uint32_t *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
     uint32_t team_n = 0;             // teams of a launch
     bool team_attr = false;          // dynamic LDS limit of k_push_team raised
     bool team_dirty = false;         // a launch ended with an error flag: its reserve accumulators (TeamDev::rsvl) may not be zero
@@ -489,7 +490,7 @@ int ensure_team(fora_ctx *c) {
     for (size_t i = 0; i < (size_t)T * T; i++) {
         off[i] = (uint32_t)at;
         at += (pair[i] + 1 + 15) & ~15ull;
-        if (at >= (1ull << 32)) return FORA_OK; // (cannot happen below 2^31 edges)
+        if (at >= (1ull << 32) || pair[i] + 1 >= (1ull << 24)) return FORA_OK; // 32-bit slots; a bucket's count is 24 bits of its barrier word: no team push for such a graph
     }
     off[(size_t)T * T] = (uint32_t)at;
     HIPCHK(c, hipMalloc(&c->d_colt, nnz * 4));
@@ -583,7 +584,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
-            HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 4));
+            HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 8));
             HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 5 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
         }
@@ -884,7 +885,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams;
-    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cnt = c->d_team_cnt;
+    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cntw = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;
@@ -906,6 +907,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     }
     if (c->team_dirty) { HIPCHK(c, hipMemsetAsync(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8, c->stream)); c->team_dirty = false; }
     HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 5 * 16 * 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, (size_t)nteams * 2 * T * T * 8, c->stream)); // no barrier tag of an earlier launch
     HIPCHK(c, hipMemsetAsync(a.slot_seq, 0xFF, (size_t)nteams * ((size_t)d.nq + 2) * 4, c->stream));
     int h = ev_begin(c, 10);
     hipLaunchKernelGGL(k_push_team, dim3(grid), dim3(TEAM_THREADS), lds, c->stream, a);

@@ -99,8 +99,8 @@ struct TeamDev {
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
     uint32_t *msg;                 // [nteams][2][off[T * T]]
     uint64_t *inct;                // [nteams][2][T][R + 64 + H] increment tables: entry e of member s = the increment of its e-th pop of the level; behind the pops: the dangling mass, then the hub sums
-    uint32_t *cnt;                 // [nteams][2][T * T] messages in bucket (s -> d) this level
-    unsigned long long *sync;      // [nteams][5][16] barrier words, one 128-byte line each; the fifth: the members' XCD census
+    unsigned long long *cntw;      // [nteams][2][T * T] the barrier words, [destination][source]: messages in bucket (s -> d) this level (24 bits) | s's pops << 24 | barrier tag << 40; zero at launch
+    unsigned long long *sync;      // [nteams][5][16] the fifth 128-byte line: the members' XCD census (the others: unused)
     uint32_t *slot_seq;            // [nteams][nq + 2] slot taken by the team in its k-th turn (TEAM_EMPTY: not yet)
     uint32_t *ctl;                 // [0] next slot, [32] abort flag
     uint32_t tail_max;             // hand the slot to k_push_tail once its frontier is at most this (and has been larger); 0: never
@@ -226,6 +226,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
+    __shared__ uint32_t s_cnt[TEAM_MAX];                     // messages source s had for me at the last barrier
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext;
     __shared__ unsigned long long s_dang, s_acc[3];
 
@@ -328,15 +329,13 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         for (uint32_t L = 0;; L++) {
             // ================= consume: the messages of the previous level that are addressed to me
             if (L > 0) {
-                const uint32_t *cin = a.cnt + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * T;
                 const uint32_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
                 const uint64_t *tin = a.inct + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * tstride;
-                // Every wave reads the T counts itself (lane s: the messages source s has for me) and takes the 128-message
-                // segments j of source s with (j + s) % 16 == its number: balanced whether the buckets are long (peak levels)
-                // or hold one segment each, and which (source, segment) its i-th one is follows from a scan of the per-source
-                // counts and a ballot -- no table in LDS, no workgroup barrier before the first message load.  CU segments per
-                // trip: all message loads in flight together (two messages per lane), then all increment gathers.
-                const uint32_t c = (uint32_t)lane < T ? __hip_atomic_load(&cin[(uint32_t)lane * T + me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; // (sc1: past L1, like every load of handed-over data)
+                // Every wave takes the 128-message segments j of source s with (j + s) % 16 == its number: balanced whether the
+                // buckets are long (peak levels) or hold one segment each, and which (source, segment) its i-th one is follows
+                // from a scan of the per-source counts (they came with the barrier) and a ballot -- no table, no search.  CU
+                // segments per trip: all message loads in flight together (two messages per lane), then all increment gathers.
+                const uint32_t c = (uint32_t)lane < T ? s_cnt[lane] : 0u; // lane s: the messages source s has for me
                 const uint32_t ns = (c + 127u) >> 7;
                 const uint32_t r0 = ((uint32_t)wid + 2u * TEAM_NW - (uint32_t)lane % TEAM_NW) % TEAM_NW; // my first segment of source `lane`
                 const uint32_t kmine = ns > r0 ? (ns - r0 + TEAM_NW - 1) / TEAM_NW : 0u;
@@ -664,27 +663,31 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     mout[s_moff[tg >> TEAM_LBITS] + atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
                 }
             }
-            __syncthreads();
-            if ((uint32_t)tid < T) (a.cnt + ((uint64_t)team * 2 + (g & 1u)) * T * T)[me * T + tid] = s_fill[tid];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message, table and count stores have completed
-            __syncthreads();
-            // ================= the team's barrier; the level's frontier size comes with it
-            if (tid == 0) {
-                if (!same_xcd) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                unsigned long long *wd = &sync[(g & 3u) * 16];
-                __hip_atomic_fetch_add(wd, (1ull << 32) | (unsigned long long)s_ncross, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long v = 0;
-                const bool ok = team_wait(a, a.err, [&] { v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (uint32_t)(v >> 32) == T; });
-                if (!same_xcd) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (me == 0) __hip_atomic_store(&sync[((g + 2) & 3u) * 16], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // dead since barrier g - 1
-                s_F = (uint32_t)v;
-                s_ok = ok ? 1u : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message and table stores have completed
+            __syncthreads();                                 // (and s_fill is final)
+            // ================= the team's barrier IS the hand-over of the counts: member s writes one word per destination d --
+            // messages in bucket (s -> d) | its pops of the level << 24 | a tag of the barrier's number << 40 -- and waits until
+            // the T words addressed to it carry the tag.  (First form: counts stored, waited for, then an atomic arrival on a
+            // shared word, a poll, and a load of the counts on the other side: three dependent round trips more per level.)
+            const uint32_t tag = (g + 1u) & 0xFFFFFFu;
+            unsigned long long *cw = a.cntw + ((uint64_t)team * 2 + (g & 1u)) * T * T; // [destination][source]
+            if (!same_xcd) {
+                if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                __syncthreads();
+            }
+            if ((uint32_t)tid < T)
+                __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)s_fill[tid] | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wid == 0) {
+                unsigned long long wv = 0;
+                const bool ok = team_wait(a, a.err, [&] {
+                    if ((uint32_t)lane < T) wv = __hip_atomic_load(&cw[me * T + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return __all((uint32_t)lane >= T || (uint32_t)(wv >> 40) == tag) != 0;
+                });
+                if (!same_xcd) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                if ((uint32_t)lane < T) s_cnt[lane] = (uint32_t)wv & 0xFFFFFFu;
+                const uint32_t pops = wave_incl_scan_add((uint32_t)lane < T ? (uint32_t)(wv >> 24) & 0xFFFFu : 0u);
+                if (lane == 63) { s_F = pops; s_ok = ok ? 1u : 0u; }
             }
             __syncthreads();
             TSTAMP(5);
