@@ -59,6 +59,9 @@ constexpr int TEAM_NIT = (TEAM_R_CAP + TEAM_THREADS - 1) / TEAM_THREADS; // swee
 #ifndef FORA_TEAM_CU
 #define FORA_TEAM_CU 4
 #endif
+#ifndef FORA_TEAM_DRAW
+#define FORA_TEAM_DRAW 4 // 64-id groups a wave draws at a time
+#endif
 #ifndef FORA_TEAM_STAGE
 #define FORA_TEAM_STAGE 0 // 1: a chunk's messages leave sorted by destination through a wave-private LDS stage (measured: not faster)
 #endif
@@ -536,10 +539,10 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         if (gcur == gend) {
                             if (drained) break;
                             uint32_t g4 = 0;
-                            if (lane == 0) g4 = atomicAdd(&s_gnext, 4u);
-                            g4 = (uint32_t)__shfl((int)g4, 0);
+                            if (lane == 0) g4 = atomicAdd(&s_gnext, (uint32_t)FORA_TEAM_DRAW);
+                            g4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g4);
                             if (g4 >= ngroups) { drained = true; break; }
-                            gcur = g4; gend = min(g4 + 4u, ngroups);
+                            gcur = g4; gend = min(g4 + (uint32_t)FORA_TEAM_DRAW, ngroups);
                         }
                         const uint32_t gi = gcur++;
                         const unsigned long long mk = s_gmask[gi];
@@ -665,13 +668,18 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
                     uint32_t eb = 0, dgh = 0, ent = 0, c0 = 0;
                     uint64_t hinc = 0;
-                    for (bool found = false; !found;) { // the row of chunk k (it may still be on its way into the list)
+                    for (bool found = false; !found;) { // the row of chunk k (it may still be on its way into the list): lane h looks at entries h, h + 64
                         const uint32_t nh = min(__atomic_load_n(&s_nheavy, __ATOMIC_RELAXED), (uint32_t)TEAM_NHEAVY);
-                        for (uint32_t h = 0; h < nh; h++) {
-                            const uint32_t dg = __atomic_load_n(&h_deg[h], __ATOMIC_ACQUIRE);
-                            if (!dg) continue;
-                            const uint32_t cs = h_cstart[h];
-                            if (k >= cs && k < cs + (dg + TEAM_CHUNK - 1) / TEAM_CHUNK) { eb = h_ebeg[h]; dgh = dg; ent = h_ent[h] << TEAM_LBITS; hinc = h_inc[h]; c0 = (k - cs) * TEAM_CHUNK; found = true; break; }
+                        for (uint32_t hb = 0; hb < nh && !found; hb += 64) {
+                            const uint32_t h = hb + lane;
+                            const uint32_t dg = h < nh ? __atomic_load_n(&h_deg[h], __ATOMIC_ACQUIRE) : 0u;
+                            const uint32_t cs = dg ? h_cstart[h] : 0u;
+                            const unsigned long long hit = __ballot(dg && k >= cs && k < cs + (dg + TEAM_CHUNK - 1) / TEAM_CHUNK);
+                            if (hit) {
+                                const uint32_t hs = hb + (uint32_t)__ffsll((long long)hit) - 1u;
+                                eb = h_ebeg[hs]; dgh = h_deg[hs]; ent = h_ent[hs] << TEAM_LBITS; hinc = h_inc[hs]; c0 = (k - h_cstart[hs]) * TEAM_CHUNK;
+                                found = true;
+                            }
                         }
                     }
                     uint32_t word[TEAM_EPT], dst[TEAM_EPT];
