@@ -62,6 +62,7 @@ struct Tunables {
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
     int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
+    int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -71,7 +72,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -123,6 +124,7 @@ struct fora_ctx {
     uint32_t *d_colt = nullptr, *d_team_off = nullptr, *d_team_n2l = nullptr, *d_team_l2n = nullptr;
     uint32_t *d_team_hubtgt = nullptr;
     uint32_t team_H = 0, team_hubs_opt = 0;
+    uint16_t *d_team_rlog_id = nullptr; uint64_t *d_team_rlog_val = nullptr; uint32_t team_rlog_cap = 0; // reserve logs (TeamDev::rlog_id)
     uint64_t *d_team_rowl = nullptr, *d_team_rsvl = nullptr; // rows by local id (graph); reserve accumulators by local id (workspace)
     uint16_t *d_team_deg16 = nullptr;
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
@@ -267,7 +269,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
-    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_rsvl); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
+    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_rsvl); dfree(c->d_team_rlog_id); dfree(c->d_team_rlog_val); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -584,6 +586,9 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
+            c->team_rlog_cap = 1u << 17; // pops of one member in one slot (ws-sized graph at eps 0.5: 43 k on average); beyond it: rsvl
+            HIPCHK(c, hipMalloc(&c->d_team_rlog_id, (size_t)nteams * T * c->team_rlog_cap * 2));
+            HIPCHK(c, hipMalloc(&c->d_team_rlog_val, (size_t)nteams * T * c->team_rlog_cap * 8));
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 8));
             HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 5 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
@@ -885,7 +890,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams;
-    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cntw = c->d_team_cnt;
+    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.rlog_id = c->d_team_rlog_id; a.rlog_val = c->d_team_rlog_val; a.rlog_cap = c->opt_.team_log == 0 ? 0u : c->opt_.team_log > 0 ? std::min<uint32_t>((uint32_t)c->opt_.team_log, c->team_rlog_cap) : c->team_rlog_cap; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cntw = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;

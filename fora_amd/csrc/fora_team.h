@@ -94,6 +94,13 @@ struct TeamDev {
     const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first edge << 32: one load per pop, by LOCAL id
     uint64_t *rsvl;                // [nteams][T][R] reserve a member's nodes collect during the slot's push, by local id (all zero between slots): with
                                    // the row word above a pop is ONE round trip of two coalesced loads -- through l2n and the slot's slab it was two dependent ones
+    // Reserve LOG: a pop's reserve (algo.h:986-989) is not added to the node's accumulator when it happens (a load and a
+    // store of a random 8-byte word per pop: a fifth of the kernel's L2 requests) -- the member appends (local id, amount) to
+    // its log of the slot with two coalesced stores, and at the hand-over, when its LDS no longer holds the residue, replays
+    // the log into that LDS and writes the sums to the slot's ppr slab.  A log that is full sends the pop to rsvl as before.
+    uint16_t *rlog_id;             // [nteams][T][rlog_cap]
+    uint64_t *rlog_val;            // [nteams][T][rlog_cap]
+    uint32_t rlog_cap;
     // Hub pre-aggregation: an edge whose target is one of the H nodes of largest in-degree (colt word 0x80000000 | hub) adds
     // its increment to the member's LDS sum of that hub; after the level's rows every non-zero sum leaves as ONE message
     // (its own entry of the increment table).  On the ws-sized graph 27 % of all edges end at the top 1024 nodes.
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
-    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort;
+    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf;
     __shared__ unsigned long long s_dang, s_acc[3];
 
     const uint32_t T = a.T, R = a.R;
@@ -255,6 +262,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     const uint32_t *l2n = a.l2n + (uint64_t)me * R;
     const uint64_t *rowl = a.rowl + (uint64_t)me * R;
     uint64_t *rsvl = a.rsvl + ((uint64_t)team * T + me) * R;
+    uint16_t *rlog_id = a.rlog_id + ((uint64_t)team * T + me) * a.rlog_cap;
+    uint64_t *rlog_val = a.rlog_val + ((uint64_t)team * T + me) * a.rlog_cap;
     unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
     for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
@@ -324,7 +333,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         const uint32_t src_local = src_word == TEAM_EMPTY ? R : (src_word & TEAM_LMASK); // no in-edge: the spare id
         uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
         uint32_t peak = 0, nlev = 0;
+        uint32_t logbase = 0;     // my pops of the slot's levels so far = entries of my reserve log
         bool final_round = false;
+        if (tid == 0) s_rsvovf = 0;
 
 #ifdef FORA_STAMPS_LEVELS
         long long lv_t_ = clock64();
@@ -508,14 +519,35 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 }
                 for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
                     const uint32_t v = l2n[l];
-                    const uint64_t rs = rsvl[l];
                     if (v != TEAM_EMPTY) a.residue[slab + v] = res[l];
-                    if (rs) { a.ppr[slab + v] = rs; rsvl[l] = 0; } // the reserve collected by local id -> the slot's slab (zero there so far)
                     res[l] = 0;
                 }
                 if (tid == 0) { // (the same thread that may have handed the spare id over)
                     if (me == src_owner && src_word == TEAM_EMPTY) a.residue[slab + src] = res[R];
                     res[R] = 0;
+                }
+                __syncthreads();
+                // the reserve log of the slot -> sums per local id in the (now empty) LDS -> the slot's ppr slab (zero there so far)
+                const uint32_t nlog = min(logbase, a.rlog_cap);
+                for (uint32_t i0 = 0; i0 < nlog; i0 += 8 * TEAM_THREADS) { // (eight entries per thread in flight)
+                    uint64_t val[8];
+                    uint32_t id[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t i = i0 + k * TEAM_THREADS + tid;
+                        val[k] = i < nlog ? rlog_val[i] : 0ull;
+                        id[k] = i < nlog ? rlog_id[i] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (val[k]) atomicAdd((unsigned long long *)&res[id[k]], (unsigned long long)val[k]);
+                }
+                __syncthreads();
+                const bool ovf = s_rsvovf != 0;
+                for (uint32_t l = tid; l < R; l += TEAM_THREADS) {
+                    uint64_t rs = res[l];
+                    if (ovf) { const uint64_t o = rsvl[l]; if (o) { rs += o; rsvl[l] = 0; } }
+                    if (rs) { a.ppr[slab + l2n[l]] = rs; res[l] = 0; }
                 }
                 TSTAMP(6);
                 break;
@@ -560,7 +592,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const uint32_t l = list[lane];
                         const bool spare = l == R; // the source without in-edges: no local tables
                         const uint64_t rw = spare ? 0ull : rowl[l];
-                        const uint64_t rsv_old = spare ? a.ppr[slab + src] : rsvl[l];
+                        const uint32_t logi = logbase + ebase + (uint32_t)lane;     // my entry of the reserve log
+                        const bool direct = spare || logi >= a.rlog_cap;           // (rare) straight to the accumulator
+                        const uint64_t rsv_old = !direct ? 0ull : spare ? a.ppr[slab + src] : rsvl[l];
                         const uint64_t ri = spare ? a.rowinfo[src] : 0ull;
                         const uint64_t rr = res[l];
                         res[l] = 0;                                       // algo.h:984-985
@@ -568,7 +602,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         if (!spare && deg == 8191u) deg = a.deg[(uint32_t)rw & 0x7FFFFu]; // a hub: its exact degree
                         uint64_t rsv_add, dang;
                         const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                        if (rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else rsvl[l] = rsv_old + rsv_add; } // algo.h:986-989 (this member owns the node)
+                        if (logi < a.rlog_cap) { rlog_val[logi] = direct ? 0ull : rsv_add; rlog_id[logi] = direct ? (uint16_t)0 : (uint16_t)l; } // algo.h:986-989, see TeamDev::rlog_id (the spare id's pop leaves an empty entry)
+                        if (!direct) {}
+                        else if (rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else { rsvl[l] = rsv_old + rsv_add; s_rsvovf = 1u; } } // (this member owns the node)
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
                         ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
                         cnt = inc ? deg : 0u;
@@ -725,6 +761,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if ((uint32_t)tid < T)
                 __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)s_fill[tid] | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            logbase += s_ncross;
             __syncthreads(); // (s_fill / s_ncross are zeroed in the sweep of the next level)
             TSTAMP(5);
 #ifdef FORA_STAMPS_LEVELS

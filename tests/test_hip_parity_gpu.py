@@ -432,19 +432,22 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
-@pytest.mark.parametrize("size,tail,xcd,tmax", [(0, 0, 1, 0), (0, -1, 1, 0), (4, 0, 1, 0), (4, 64, 0, 0), (16, 300, 1, 0), (32, 0, 1, 0),
-                                                (32, 2000, 0, 0), (1, 16, 1, 3), (8, 1, 1, 1)])
+@pytest.mark.parametrize("size,tail,xcd,tmax,log", [(0, 0, 1, 0, -1), (0, -1, 1, 0, -1), (4, 0, 1, 0, 0), (4, 64, 0, 0, -1), (16, 300, 1, 0, 40),
+                                                    (32, 0, 1, 0, -1), (32, 2000, 0, 0, 7), (1, 16, 1, 3, 1000), (8, 1, 1, 1, -1), (2, 0, 2, 0, 100)])
 @pytest.mark.parametrize("gname", ["small_dangling", "small"])
-def test_team_push_bit_exact(engine, oracle, request, gname, size, tail, xcd, tmax):
+def test_team_push_bit_exact(engine, oracle, request, gname, size, tail, xcd, tmax, log):
     """k_push_team (fora_team.h): the residue of a slot stays in the LDS of a team of workgroups for the whole push; levels
     are the twin's.  Team sizes 1 ... 32 (option team_size; 0 = the fewest members whose LDS holds the graph), the
     hand-over to k_push_tail at several frontier sizes (team_tail; 0 = the team runs the push to its end), both placements
-    of the members (team_xcd) and fewer teams than slots (team_max) all give the twin's bits."""
+    of the members (team_xcd; 2 = with the fences of members on different XCDs), fewer teams than slots (team_max) and
+    reserve logs of every size (team_log: none, a few entries -- most pops go to the accumulators --, the default) all
+    give the twin's bits."""
     g = request.getfixturevalue(gname)
     engine.set_option("team", 1)
     engine.set_option("team_size", size)
     engine.set_option("team_xcd", xcd)
     engine.set_option("team_max", tmax)
+    engine.set_option("team_log", log)
     if tail >= 0:
         engine.set_option("team_tail", tail)
         engine.set_option("tail_always", 1)  # hand over as soon as the frontier is that small, also while it is still growing
