@@ -62,9 +62,6 @@ constexpr int TEAM_NIT = (TEAM_R_CAP + TEAM_THREADS - 1) / TEAM_THREADS; // swee
 #ifndef FORA_TEAM_DRAW
 #define FORA_TEAM_DRAW 4 // 64-id groups a wave draws at a time
 #endif
-#ifndef FORA_TEAM_STAGE
-#define FORA_TEAM_STAGE 0 // 1: a chunk's messages leave sorted by destination through a wave-private LDS stage (measured: not faster)
-#endif
 constexpr int TEAM_EPT = FORA_TEAM_EPT;       // consecutive edges a lane gathers per chunk
 constexpr int TEAM_CHUNK = 64 * TEAM_EPT;     // messages of a chunk = entries of a wave's stage
 constexpr uint32_t TEAM_LMASK = (1u << TEAM_LBITS) - 1u;
@@ -160,63 +157,20 @@ constexpr uint32_t TEAM_HEAVY = FORA_TEAM_HEAVY; // rows of more edges are relax
 constexpr int TEAM_NHEAVY = 128;
 constexpr int TEAM_MAXGROUPS = 256;   // 64-id groups of a member at most, the spare id's included
 
-// A wave's stage: the messages of a chunk sorted by destination member (counting sort over <= 32 keys: an LDS histogram
-// gives every message its rank, one atomic per (chunk, destination) on the workgroup's fill counters gives the run its
-// place in the bucket), written out with consecutive lanes on consecutive words of a run.
-struct TeamStage {
-    uint32_t msg[TEAM_CHUNK];
-    uint8_t dst[TEAM_CHUNK];
-    uint32_t hist[TEAM_MAX], offs[TEAM_MAX], delta[TEAM_MAX];
-};
-// word[k] / dst[k]: this lane's messages (dst TEAM_EMPTY: none); s_fill, s_moff: the workgroup's per-destination counters / bucket starts
-__device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT],
-                                          uint32_t *s_fill, const uint32_t *s_moff, uint32_t *mout, uint32_t T, int lane) {
-#if !FORA_TEAM_STAGE
-    // direct form: every message takes its place from the workgroup's fill counter and is stored on its own
-    uint32_t rk[TEAM_EPT], first[TEAM_EPT]; // (all four counter round trips in flight together, then the stores)
+// word[k] / dst[k]: this lane's messages of a chunk (dst TEAM_EMPTY: none).  s_fill[d]: the next free slot of my bucket
+// (me -> d) in the level's message buffer -- one returning LDS add per message; all four in flight together, then the stores.
+// (Measured and dropped: the chunk's messages sorted by destination in a wave-private LDS stage and stored as coalesced
+// runs -- 82-84 ms against 75 at the time: the sort costs more instructions than the scattered stores cost requests.)
+__device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout) {
+    uint32_t slot[TEAM_EPT];
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++) {
-        rk[k] = 0; first[k] = 0;
-        if (dst[k] != TEAM_EMPTY) { rk[k] = atomicAdd(&s_fill[dst[k]], 1u); first[k] = s_moff[dst[k]]; }
+        slot[k] = 0;
+        if (dst[k] != TEAM_EMPTY) slot[k] = atomicAdd(&s_fill[dst[k]], 1u);
     }
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++)
-        if (dst[k] != TEAM_EMPTY) mout[first[k] + rk[k]] = word[k];
-    return;
-#endif
-    if (lane < TEAM_MAX) st.hist[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t rank[TEAM_EPT];
-#pragma unroll
-    for (int k = 0; k < TEAM_EPT; k++) {
-        rank[k] = 0;
-        if (dst[k] != TEAM_EMPTY) rank[k] = atomicAdd(&st.hist[dst[k]], 1u);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t c = (uint32_t)lane < T ? st.hist[lane] : 0u;
-    uint32_t total;
-    const uint32_t ex = wave_excl_scan(c, total);
-    if ((uint32_t)lane < T) {
-        const uint32_t gp = c ? atomicAdd(&s_fill[lane], c) : 0u;
-        st.offs[lane] = ex;
-        st.delta[lane] = s_moff[lane] + gp - ex; // bucket slot of stage entry i of this destination: delta + i
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < TEAM_EPT; k++) {
-        if (dst[k] != TEAM_EMPTY) {
-            const uint32_t slot = st.offs[dst[k]] + rank[k];
-            st.msg[slot] = word[k];
-            st.dst[slot] = (uint8_t)dst[k];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < TEAM_EPT; j++) {
-        const uint32_t i = j * 64 + lane;
-        if (i < total) mout[st.delta[st.dst[i]] + i] = st.msg[i];
-    }
-    __builtin_amdgcn_wave_barrier();
+        if (dst[k] != TEAM_EMPTY) mout[slot[k]] = word[k];
 }
 
 // grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * (R + 1) bytes.
@@ -226,7 +180,6 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
 // time on their own (prefix sums by wave scan), so the sixteen waves of a member overlap each other's memory round trips.
 __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev a) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
     extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id; then [H] hub sums of the level
-    __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
     __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY], h_cstart[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree (written last: 0 = not there yet), first chunk number
@@ -235,7 +188,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint64_t h_inc[TEAM_NHEAVY];
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
-    __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // messages I have put into bucket (me -> d) this level; its first slot
+    __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // next free slot of my bucket (me -> d) in the level's message buffer; its first slot
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf;
     __shared__ unsigned long long s_dang, s_acc[3];
 
@@ -267,7 +220,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
     uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
     for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
-    if (tid < (int)T) s_moff[tid] = a.off[me * T + tid];
+    if (tid < TEAM_MAX) s_moff[tid] = tid < (int)T ? a.off[me * T + tid] : 0u;
     const uint32_t coffv = (uint32_t)lane < T ? a.off[(uint32_t)lane * T + me] : 0u; // first slot of bucket (lane -> me)
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
     uint32_t dgp[(TEAM_NIT + 1) / 2];
@@ -436,7 +389,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             // ================= sweep: who is at or over the threshold (algo.h:1012).  Thread t looks at local ids
             // it * 1024 + t, i.e. wave w at the 64-id groups it * 16 + w; no global load (out-degrees in registers).
             uint32_t crossmask = 0;
-            if (tid < TEAM_MAX) s_fill[tid] = 0;
+            if (tid < TEAM_MAX) s_fill[tid] = s_moff[tid];
             if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; s_hchunks = 0; s_hnext = 0; s_wdone = 0; s_hubent = 0; }
             if (tid < TEAM_NHEAVY) h_deg[tid] = 0;
             if (L > 0) {
@@ -562,7 +515,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 uint16_t *list = w_list[wid];
                 uint64_t *winc = w_inc[wid];
                 uint8_t *mark = w_mark[wid];
-                TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
                 uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
                 if (L == 0) { drained = true; if (me == src_owner && wid == 0) { if (lane == 0) list[0] = (uint16_t)src_local; npend = 1; } }
@@ -678,7 +630,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                 dst[k] = TEAM_EMPTY;
                             }
                         }
-                        team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
+                        team_emit(word, dst, s_fill, mout);
                     }
                     TSTAMP(3);
                 }
@@ -689,7 +641,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if (lane == 0 && my_dang) atomicAdd(&s_dang, (unsigned long long)my_dang);
             { // heavy rows, chunk by chunk, until every wave is through its own rows and no chunk is left: consecutive lanes on
               // consecutive edges.  (First form: all heavy rows after a barrier -- the waves that had finished early waited there.)
-                TeamStage &st = w_stage[FORA_TEAM_STAGE ? wid : 0];
                 if (lane == 0) atomicAdd(&s_wdone, 1u);
                 for (;;) {
                     uint32_t k = TEAM_EMPTY, fin = 0;
@@ -729,7 +680,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             else { dst[kk] = w >> TEAM_LBITS; word[kk] = (w & TEAM_LMASK) | ent; }
                         }
                     }
-                    team_emit(st, word, dst, s_fill, s_moff, mout, T, lane);
+                    team_emit(word, dst, s_fill, mout);
                 }
             }
             TSTAMP(6);
@@ -738,7 +689,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if (tid == 0 && s_dang) { // one more table entry, one more message
                 const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
                 tout[ent] = s_dang;
-                mout[s_moff[src_owner] + pos] = src_local | (ent << TEAM_LBITS);
+                mout[pos] = src_local | (ent << TEAM_LBITS);
             }
             for (uint32_t h = tid; h < H; h += TEAM_THREADS) { // the hubs' sums of this level: one message each
                 const unsigned long long hv = s_hub[h];
@@ -746,7 +697,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     s_hub[h] = 0;
                     const uint32_t tg = a.hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
                     tout[ent] = hv;
-                    mout[s_moff[tg >> TEAM_LBITS] + atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
+                    mout[atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message and table stores have completed
@@ -759,7 +710,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 __syncthreads();
             }
             if ((uint32_t)tid < T)
-                __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)s_fill[tid] | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
+                __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)(s_fill[tid] - s_moff[tid]) | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             logbase += s_ncross;
             __syncthreads(); // (s_fill / s_ncross are zeroed in the sweep of the next level)
