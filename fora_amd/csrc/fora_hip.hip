@@ -62,6 +62,7 @@ struct Tunables {
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
     int64_t team_max = 0;        // teams per launch at most (0: one member per CU); tests
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
+    int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
@@ -72,7 +73,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -662,6 +663,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     if (c->binned && c->d_col_hub && c->d_hubsum && c->hub_shift == bin_shift(c) && c->pbins >= c->nbins) { // one pass per level only: the passes of larger graphs read a row-sorted copy
         d.col_hub = c->d_col_hub; d.hub_node = c->d_hub_node; d.hub_first = c->d_hub_first; d.hubsum = c->d_hubsum; d.hubs = c->hubs;
         d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
+        d.tail_hubs = c->opt_.tail_hubs != 0 && (size_t)c->hubs * 8 <= 40960 ? 1u : 0u; // (k_push_tail: 20 KiB of static LDS + the sums within 64 KiB)
     }
     d.defer_k = c->binned && c->d_dl ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
     d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
@@ -734,6 +736,8 @@ int check_dev_err(fora_ctx *c) {
 // Level loop of the push for the slots already initialised (level-0 frontier in place).
 // Launches run ahead of the host by SPEC levels: an empty level costs a few near-empty
 // launches, a host round trip per level would cost more.
+static inline size_t tail_lds(const Dev &d) { return d.tail_hubs && d.col_hub ? (size_t)d.hubs * 8 : 0; } // k_push_tail's dynamic LDS
+
 int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, int level_cap = 0, bool round_start = false) {
     const int nq = d.nq;
     if (round_start && c->binned && level_cap <= 0 && d.rounds <= 1 && c->opt_.tail != 0) {
@@ -751,7 +755,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
         if (fmax == 0) { if (levels_run) *levels_run = 0; return FORA_OK; }
         if (fmax <= tail_max) {
             int h = ev_begin(c, 9);
-            hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, d, 0, 0);
+            hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), tail_lds(d), c->stream, d, 0, 0);
             ev_end(c, h);
             c->timing.levels++;
             if (levels_run) *levels_run = 1;
@@ -858,7 +862,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                     int h = ev_begin(c, 9);
                     Dev dt = d;
                     if (d.rounds > 1) dt.defer_k = 0;
-                    hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), 0, c->stream, dt, next, remaining);
+                    hipLaunchKernelGGL(k_push_tail, dim3(nq), dim3(TAIL_THREADS), tail_lds(dt), c->stream, dt, next, remaining);
                     ev_end(c, h);
                     c->timing.levels++;
                 }
@@ -920,7 +924,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     c->timing.levels++;
     if (a.tail_max) {
         h = ev_begin(c, 9);
-        hipLaunchKernelGGL(k_push_tail, dim3(d.nq), dim3(TAIL_THREADS), 0, c->stream, d, 0, 0);
+        hipLaunchKernelGGL(k_push_tail, dim3(d.nq), dim3(TAIL_THREADS), tail_lds(d), c->stream, d, 0, 0);
         ev_end(c, h);
         c->timing.levels++;
     }

@@ -235,6 +235,7 @@ struct Dev {
     const uint32_t *hub_first; // [nbins + 1]
     uint64_t *hubsum;          // [slot][sub][hubs]
     uint32_t hubs, hub_min;
+    uint32_t tail_hubs;     // != 0: k_push_tail sums the increments for hubs in LDS too (its launches pass hubs * 8 bytes of dynamic LDS)
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
@@ -1002,11 +1003,18 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
     __shared__ uint32_t s_next, s_count, s_ndue, s_nwait, s_real;
     __shared__ unsigned long long s_dang;
     constexpr uint32_t HOLE = 0x80000000u; // list entry of a node that crossed but waits a level (bounded deferral): skipped by the pops
+    // The chip takes 23 G returning atomics per second whatever their addresses (profiles/r01_atomics_microbench.txt), and
+    // this kernel issues little else: with a hub copy of the graph (Dev::col_hub) the increments for the hubs -- 45 % of all
+    // relaxations on the ws-sized graph -- are summed in LDS and reach the residue as one atomic per touched hub and level.
+    extern __shared__ unsigned long long s_hubt[]; // [d.hubs] when hubmode
+    const bool hubmode = d.tail_hubs && d.col_hub;
+    const int32_t *colsrc = hubmode ? d.col_hub : d.col;
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t src = (uint32_t)d.src[q];
     const int dk = max_levels > 0 ? 0 : d.defer_k; // capped runs (power iteration) keep plain levels
+    if (hubmode) for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS) s_hubt[h] = 0;
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
     uint32_t levels_run = 0;
@@ -1114,8 +1122,16 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
                     if (e < total) {
                         while (s_pref[lo + 1] <= e) lo++; // nodes without edges
                         inc[k] = s_inc[lo];
-                        w[k] = (uint32_t)d.col[s_ebeg[lo] + (e - s_pref[lo])];
+                        w[k] = (uint32_t)colsrc[s_ebeg[lo] + (e - s_pref[lo])];
                     }
+                }
+                if (hubmode) {
+#pragma unroll
+                    for (int k = 0; k < TAIL_EPT; k++)
+                        if (w[k] != 0xFFFFFFFFu && (w[k] & 0x80000000u)) { // a hub: summed here, added to its residue at the end of the level
+                            atomicAdd(&s_hubt[w[k] & 0x7FFFFFFFu], (unsigned long long)inc[k]);
+                            w[k] = 0xFFFFFFFFu;
+                        }
                 }
 #pragma unroll
                 for (int k = 0; k < TAIL_EPT; k++) {
@@ -1137,6 +1153,20 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
                 }
             }
             __syncthreads();
+        }
+        if (hubmode) { // the hubs' sums of the level (every add to s_hubt is behind the tile loop's last barrier)
+            for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS) {
+                const uint64_t hv = s_hubt[h];
+                if (!hv) continue;
+                s_hubt[h] = 0;
+                const uint32_t w = d.hub_node[h];
+                const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)hv);
+                const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                if (old < thr && old + hv >= thr) { // (algo.h:1012-1015: crossed in this level)
+                    const uint32_t pos = atomicAdd(&s_next, 1u);
+                    if (pos < (uint32_t)d.n) out[pos] = w; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                }
+            }
         }
         // ---- dangling mass back to the source (algo.h:994-998)
         if (tid == 0 && s_dang) {
