@@ -8,16 +8,17 @@
 // round-robin (owner(v) = (v >> 6) % T) and only nodes that HAVE in-edges get a local id (nothing ever lands on the
 // others; the slot's source, if it is one of them, uses the spare id R).  A level is
 //
-//   consume   the 4-byte messages the T members wrote for me in the previous level: ds_add_u64 into my residue
+//   consume   the 4-byte messages the members wrote for me in the previous level: ds_add_u64 into my residue.  There is
+//             no barrier between the levels: a member ends its level by writing one tagged word per destination (count |
+//             pops | level), and every wave of the destination polls its T words and consumes the buckets of the sources
+//             that are through while the slower ones are still emitting
 //   sweep     my residue words against their thresholds (algo.h:1012): whoever is at or over it is this level's frontier
 //             -- after a level's pops every residue is under its threshold, so "crossed during the level" and "is at or
 //             over it now" are the same set.  The out-degrees a thread compares with sit in its registers for the whole
 //             launch (16 bits each): the sweep issues no global load
-//   pop+emit  every wave on its own, 64 frontier nodes at a time: residue -> reserve + increment (algo.h:983-1002, one
-//             lane per node), then their out-edges from a copy of col that names every target as (owner, local id); the
-//             256 messages of a chunk are sorted by owner in a wave-private LDS stage and leave as one run per bucket
-//   barrier   ONE device-scope barrier of the team per level (arrive = atomic add of 2^32 + my pops on a word that
-//             rotates over four; the sum of the pops is the level's frontier size, read by every member)
+//   pop+emit  every wave on its own, 64 frontier nodes at a time: residue -> reserve log + increment (algo.h:983-1002,
+//             one lane per node), then their out-edges from a copy of col that names every target as (owner, local id):
+//             one returning LDS add gives a message its slot in the bucket (me -> owner), one store writes it
 //
 // No residue slab traffic, no frontier lists, no launches, no host round trips per level.  A bucket (s -> d) can never
 // overflow: a level relaxes every edge at most once, so its capacity is the number of edges from s's nodes to d's
@@ -30,11 +31,8 @@
 // increment table of the level (one 8-byte word per pop, written once, coalesced; the consumer gathers it from L2 --
 // a bucket's messages follow the producer's pop order, so neighbouring lanes gather neighbouring entries).
 //
-// What was measured on the way (ws-sized graph, 1000 queries, push only; bucketed kernels 75 ms): 8-byte messages with
-// the increment inline and block-wide batches of 1024 pops 95 ms (one exposed HBM round trip per batch, 67 GB of messages
-// each way); waves on their own 90; 4-byte messages 82 -- at which point 3.05 G of the kernel's 5.4 G L2 requests were
-// 4-byte message stores (2.8 messages per request) and the L1 sat stalled on pending requests 58 % of its cycles
-// (profiles/r04_pmc_team_v3.txt), hence the sorted stage.
+// What was measured on the way: DESIGN.md 5.1b (ws-sized graph, 1000 queries: bucketed kernels 75 ms; first form of this
+// kernel 89 ms; 49 ms now).
 #pragma once
 #include "fora_kernels.h"
 
@@ -63,7 +61,7 @@ constexpr int TEAM_NIT = (TEAM_R_CAP + TEAM_THREADS - 1) / TEAM_THREADS; // swee
 #define FORA_TEAM_DRAW 4 // 64-id groups a wave draws at a time
 #endif
 constexpr int TEAM_EPT = FORA_TEAM_EPT;       // consecutive edges a lane gathers per chunk
-constexpr int TEAM_CHUNK = 64 * TEAM_EPT;     // messages of a chunk = entries of a wave's stage
+constexpr int TEAM_CHUNK = 64 * TEAM_EPT;     // edges of a chunk
 constexpr uint32_t TEAM_LMASK = (1u << TEAM_LBITS) - 1u;
 constexpr uint32_t TEAM_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t ERR_TEAM_TIMEOUT = 16, ERR_TEAM_CAP = 32;
@@ -582,7 +580,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     const uint32_t pre = wave_excl_scan(cnt, total);
                     TSTAMP(2);
                     // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows.  Which row an edge
-                    // belongs to comes from MARKS: every row with edges writes its number at the stage position of its first edge,
+                    // belongs to comes from MARKS: every row with edges writes its number at the chunk position of its first edge,
                     // a lane reads the marks of its edges in one word, and a wave scan ("the last mark so far") fills the gaps --
                     // about a third of the instructions of the binary search + stepping it replaces (the chunk loop is bound by
                     // its instruction count: 1.2 per edge at 1.16 CU-cycles per edge).

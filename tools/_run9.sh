@@ -1,3 +1,6 @@
-timeout 1200 python3 -m pytest tests/test_hip_parity_gpu.py tests/test_edge_cases_gpu.py -x -q -m gpu 2>&1 | tail -2
-python3 tools/pushbench.py --reps 3 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('tail_ms','team_ms','push_ms')})"
-python3 tools/pushbench.py --reps 3 --option tail_hubs=0 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('tail_hubs=0', {k:d[k] for k in ('tail_ms','team_ms','push_ms')})"
+for t in 2048 3072 4096 5120 6144 8192; do python3 tools/pushbench.py --reps 3 --option team_tail=$t | python3 -c "
+import sys,json
+for l in sys.stdin:
+    try: d=json.loads(l)
+    except Exception: print(l[:300]); continue
+    print($t, {k:d[k] for k in ('tail_ms','team_ms','push_ms')})"; done
