@@ -2708,15 +2708,17 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
         if (threadIdx.x < DG_TILE) s_pref[threadIdx.x] = pre;
         if (threadIdx.x == 0) s_pref[DG_TILE] = total;
         __syncthreads();
-        const uint32_t wend = (uint32_t)(((uint64_t)total * (wid + 1)) / NW);
-        uint32_t wptr = (uint32_t)(((uint64_t)total * wid) / NW); // next unassigned walk of this wave
-        uint32_t cur_item = 0;                                      // item holding walk wptr (wave-uniform)
+        // (wave-uniform bookkeeping in scalar registers: what comes from LDS or from the thread id goes through readfirstlane)
+        const uint32_t total_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)total), wid_u = (uint32_t)__builtin_amdgcn_readfirstlane(wid);
+        const uint32_t wend = (uint32_t)(((uint64_t)total_u * (wid_u + 1)) / NW);
+        uint32_t wptr = (uint32_t)(((uint64_t)total_u * wid_u) / NW); // next unassigned walk of this wave
+        uint32_t cur_item = 0;                                        // item holding walk wptr (wave-uniform)
         {
             uint32_t hi = DG_TILE;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 const uint32_t mid = (cur_item + hi) >> 1;
-                if (s_pref[mid] <= wptr) cur_item = mid; else hi = mid;
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[mid]) <= wptr) cur_item = mid; else hi = mid;
             }
         }
         bool active = false;
@@ -2745,7 +2747,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                 }
                 const uint32_t want = (uint32_t)__popcll(idle);
                 wptr += want < avail ? want : avail;
-                while (wptr < wend && s_pref[cur_item + 1] <= wptr) cur_item++;
+                while (wptr < wend && (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[cur_item + 1]) <= wptr) cur_item++;
             }
             if (active) {
                 uint32_t rw[4];

@@ -1,6 +1,2 @@
-for t in 2048 3072 4096 5120 6144 8192; do python3 tools/pushbench.py --reps 3 --option team_tail=$t | python3 -c "
-import sys,json
-for l in sys.stdin:
-    try: d=json.loads(l)
-    except Exception: print(l[:300]); continue
-    print($t, {k:d[k] for k in ('tail_ms','team_ms','push_ms')})"; done
+timeout 900 python3 -m pytest tests/test_hip_parity_gpu.py -x -q -m gpu -k "walk or query" 2>&1 | tail -2
+python3 tools/pushbench.py --reps 3 --mode query | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('walk_ms','walk_alloc_ms','walk_accum_ms','push_ms','batch_ms')})"
