@@ -710,8 +710,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if ((uint32_t)tid < T)
                 __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)(s_fill[tid] - s_moff[tid]) | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            logbase += s_ncross;
-            __syncthreads(); // (s_fill / s_ncross are zeroed in the sweep of the next level)
+            logbase += s_ncross; // (s_fill / s_ncross are zeroed in the sweep of the next level: behind the barrier that closes its consume)
             TSTAMP(5);
 #ifdef FORA_STAMPS_LEVELS
             if (tid == 0) { const long long n_ = clock64(); atomicAdd(&a.stamps[L < 31 ? L : 31], (unsigned long long)(n_ - lv_t_)); lv_t_ = n_; }
