@@ -2646,8 +2646,14 @@ template <bool NZH, bool BITS32, bool XL>
 __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(FORA_DG_WPE, 8))) k_walk_dg(Dev d, uint32_t round) {
     constexpr int NW = DG_THREADS / 64;
     extern __shared__ uint64_t dg_lds64[]; // XL: hub accumulators [H] (u64) | first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
-    __shared__ uint64_t s_j0[DG_TILE], s_incr[DG_TILE], s_rem[DG_TILE];
-    __shared__ uint32_t s_v[DG_TILE], s_vp[DG_TILE], s_idxn[DG_TILE], s_pref[DG_TILE + 1], s_w[NW];
+    // Walk items are staged per WAVE, WT at a time: a walk that has started lives in its lane's registers, so the wave
+    // loads its next WT items as soon as the walks of the current ones are handed out -- lanes never wait for the longest
+    // walk of a tile to end, and the loop has no workgroup barrier.  (First form: 256 items per workgroup between two
+    // barriers, an eighth of their walks per wave: a tile's last walks ran on a few lanes for ~9 iterations per ~35.)
+    constexpr int WT = DG_TILE / NW;
+    static_assert(WT >= 1 && WT <= 64, "a lane loads one item of its wave's tile");
+    __shared__ uint64_t w_j0[NW][WT], w_incr[NW][WT], w_rem[NW][WT];
+    __shared__ uint32_t w_v[NW][WT], w_vp[NW][WT], w_idxn[NW][WT], w_pref[NW][WT + 1], s_w[NW];
     const int q = blockIdx.y;
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
     if (!nitems || *d.err) return;
@@ -2683,119 +2689,119 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     bool pend = false;
     uint32_t pend_node = 0;
     uint64_t pend_w = 0;
-    for (uint32_t tbase = blockIdx.x * DG_TILE; tbase < nitems; tbase += gridDim.x * DG_TILE) {
-        const uint32_t i = tbase + threadIdx.x;
-        uint32_t cnt = 0;
-        if (threadIdx.x < DG_TILE && i < nitems) {
+    uint64_t *s_j0 = w_j0[wid], *s_incr = w_incr[wid], *s_rem = w_rem[wid];
+    uint32_t *s_v = w_v[wid], *s_vp = w_vp[wid], *s_idxn = w_idxn[wid], *s_pref = w_pref[wid];
+    const uint32_t ntiles = (nitems + WT - 1) / WT;
+    uint32_t tile = blockIdx.x * NW + wid;      // the wave's next tile of WT items
+    const uint32_t tstride = gridDim.x * NW;
+    uint32_t wptr = 0, wend = 0;                // walks of the current tile: wptr .. wend - 1 are not handed out yet (wave-uniform)
+    uint32_t cur_item = 0;                      // item holding walk wptr (wave-uniform)
+    bool active = false;
+    uint32_t cur = 0, start = 0, startp = 0, t = 0;
+    uint64_t wj = 0, wgt = 0;
+    for (;;) {
+        int32_t done = -1; // endpoint (copy id) reached this iteration
+        const unsigned long long idle = __ballot(!active);
+        if (idle && wptr == wend) { // lanes are free and the tile is handed out: the next tile that has walks
+            while (wptr == wend && tile < ntiles) {
+                const uint32_t i = tile * WT + lane;
+                uint32_t cnt = 0;
+                if (lane < WT && i < nitems) {
 #ifndef FORA_DG_PLAIN_ITEMS
-            WalkItem w; // read once: keep the items out of the way of the packed targets in L2
-            {
-                const uint64_t *wp = (const uint64_t *)&items[i];
-                uint64_t x0 = NT_LOAD(wp), x2 = NT_LOAD(wp + 2), x3 = NT_LOAD(wp + 3), x4 = NT_LOAD(wp + 4), x5 = NT_LOAD(wp + 5);
-                w.j0 = x0; w.idx_pos = 0; w.incr = x2; w.rem = x3; w.q = (uint32_t)x4; w.v = (uint32_t)(x4 >> 32); w.cnt = (uint32_t)x5; w.idx_n = (uint32_t)(x5 >> 32);
-            }
+                    WalkItem w; // read once: keep the items out of the way of the packed targets in L2
+                    {
+                        const uint64_t *wp = (const uint64_t *)&items[i];
+                        uint64_t x0 = NT_LOAD(wp), x2 = NT_LOAD(wp + 2), x3 = NT_LOAD(wp + 3), x4 = NT_LOAD(wp + 4), x5 = NT_LOAD(wp + 5);
+                        w.j0 = x0; w.idx_pos = 0; w.incr = x2; w.rem = x3; w.q = (uint32_t)x4; w.v = (uint32_t)(x4 >> 32); w.cnt = (uint32_t)x5; w.idx_n = (uint32_t)(x5 >> 32);
+                    }
 #else
-            const WalkItem w = items[i];
+                    const WalkItem w = items[i];
 #endif
-            s_j0[threadIdx.x] = w.j0; s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
-            s_v[threadIdx.x] = w.v;
-            s_vp[threadIdx.x] = g.perm[w.v];
-            s_idxn[threadIdx.x] = w.idx_n;
-            cnt = w.cnt - w.idx_n;
-        }
-        uint32_t total;
-        const uint32_t pre = block_excl_scan_n<DG_THREADS>(cnt, s_w, total);
-        if (threadIdx.x < DG_TILE) s_pref[threadIdx.x] = pre;
-        if (threadIdx.x == 0) s_pref[DG_TILE] = total;
-        __syncthreads();
-        // (wave-uniform bookkeeping in scalar registers: what comes from LDS or from the thread id goes through readfirstlane)
-        const uint32_t total_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)total), wid_u = (uint32_t)__builtin_amdgcn_readfirstlane(wid);
-        const uint32_t wend = (uint32_t)(((uint64_t)total_u * (wid_u + 1)) / NW);
-        uint32_t wptr = (uint32_t)(((uint64_t)total_u * wid_u) / NW); // next unassigned walk of this wave
-        uint32_t cur_item = 0;                                        // item holding walk wptr (wave-uniform)
-        {
-            uint32_t hi = DG_TILE;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const uint32_t mid = (cur_item + hi) >> 1;
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[mid]) <= wptr) cur_item = mid; else hi = mid;
-            }
-        }
-        bool active = false;
-        uint32_t cur = 0, start = 0, startp = 0, t = 0;
-        uint64_t wj = 0, wgt = 0;
-        for (;;) {
-            int32_t done = -1; // endpoint (copy id) reached this iteration
-            const unsigned long long idle = __ballot(!active);
-            const uint32_t avail = wend - wptr;
-            if (!avail && idle == ~0ull) break;
-            if (avail && idle) {
-                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1));
-                if (!active && rank < avail) {
-                    const uint32_t e = wptr + rank;
-                    uint32_t item = cur_item;
-                    while (s_pref[item + 1] <= e) item++;
-                    const uint32_t jj = s_idxn[item] + (e - s_pref[item]); // online walks follow the indexed ones
-                    wj = s_j0[item] + jj;
-                    start = s_v[item];
-                    startp = s_vp[item];
-                    wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // (!XL: the lane's previous result already waits in pend_w)
-                    cur = startp;
-                    t = 0;
-                    if (startp >= g.zero_first) done = (int32_t)startp; // algo.h:127-129
-                    else active = true;
+                    s_j0[lane] = w.j0; s_incr[lane] = w.incr; s_rem[lane] = w.rem;
+                    s_v[lane] = w.v;
+                    s_vp[lane] = g.perm[w.v];
+                    s_idxn[lane] = w.idx_n;
+                    cnt = w.cnt - w.idx_n;
                 }
-                const uint32_t want = (uint32_t)__popcll(idle);
-                wptr += want < avail ? want : avail;
-                while (wptr < wend && (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[cur_item + 1]) <= wptr) cur_item++;
+                uint32_t total;
+                const uint32_t pre = wave_excl_scan(cnt, total);
+                if (lane < WT) s_pref[lane] = pre;
+                if (lane == 0) s_pref[WT] = total;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the wave's own LDS writes, read by its lanes below)
+                __builtin_amdgcn_wave_barrier();
+                wptr = 0; wend = total; cur_item = 0;
+                tile += tstride;
+                while (wptr < wend && (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[cur_item + 1]) <= wptr) cur_item++; // items without online walks
             }
-            if (active) {
-                uint32_t rw[4];
-                philox4x32_10(start, (uint32_t)wj,
-                              (uint32_t)((wj >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
-                              stream ^ ((t >> 9) * 0x9E3779B9u), d.seed_lo, d.seed_hi, rw);
-                if (!(NZH && t == 0) && rw[0] < d.alpha32) { // algo.h:131-133
+        }
+        const uint32_t avail = wend - wptr;
+        if (!avail && idle == ~0ull) break; // (no tile left either)
+        if (avail && idle) {
+            const uint32_t rank = __popcll(idle & ((1ull << lane) - 1));
+            if (!active && rank < avail) {
+                const uint32_t e = wptr + rank;
+                uint32_t item = cur_item;
+                while (s_pref[item + 1] <= e) item++;
+                const uint32_t jj = s_idxn[item] + (e - s_pref[item]); // online walks follow the indexed ones
+                wj = s_j0[item] + jj;
+                start = s_v[item];
+                startp = s_vp[item];
+                wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // (!XL: the lane's previous result already waits in pend_w)
+                cur = startp;
+                t = 0;
+                if (startp >= g.zero_first) done = (int32_t)startp; // algo.h:127-129
+                else active = true;
+            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            wptr += want < avail ? want : avail;
+            while (wptr < wend && (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pref[cur_item + 1]) <= wptr) cur_item++;
+            __builtin_amdgcn_wave_barrier(); // (every lane has read its item before the tile can be replaced)
+        }
+        if (active) {
+            uint32_t rw[4];
+            philox4x32_10(start, (uint32_t)wj,
+                          (uint32_t)((wj >> 32) & 0xFFFFu) | ((round & 0xFFu) << 16) | (((t >> 1) & 0xFFu) << 24),
+                          stream ^ ((t >> 9) * 0x9E3779B9u), d.seed_lo, d.seed_hi, rw);
+            if (!(NZH && t == 0) && rw[0] < d.alpha32) { // algo.h:131-133
+                done = (int32_t)cur;
+                active = false;
+            } else {
+#if defined(FORA_DG_FAKE_STEP0) // diagnostic only (wrong results): what the kernel would take if the first step of every walk hit L1
+                cur = t == 0 ? move(cur & 1023u, startp, rw[1]) : move(cur, startp, rw[1]);
+#elif defined(FORA_DG_FAKE_ALL) // diagnostic only: every step's gather from a 4-KB window (the kernel's floor without misses)
+                cur = move(cur & 1023u, startp, rw[1]);
+#else
+                cur = move(cur, startp, rw[1]);
+#endif
+                steps++;
+                if (rw[2] < d.alpha32) {
+                    t++;
                     done = (int32_t)cur;
                     active = false;
                 } else {
-#if defined(FORA_DG_FAKE_STEP0) // diagnostic only (wrong results): what the kernel would take if the first step of every walk hit L1
-                    cur = t == 0 ? move(cur & 1023u, startp, rw[1]) : move(cur, startp, rw[1]);
-#elif defined(FORA_DG_FAKE_ALL) // diagnostic only: every step's gather from a 4-KB window (the kernel's floor without misses)
-                    cur = move(cur & 1023u, startp, rw[1]);
-#else
-                    cur = move(cur, startp, rw[1]);
-#endif
-                    steps++;
-                    if (rw[2] < d.alpha32) {
-                        t++;
-                        done = (int32_t)cur;
-                        active = false;
-                    } else {
 #if defined(FORA_DG_FAKE_ALL)
-                        cur = move(cur & 1023u, startp, rw[3]);
+                    cur = move(cur & 1023u, startp, rw[3]);
 #else
-                        cur = move(cur, startp, rw[3]);
+                    cur = move(cur, startp, rw[3]);
 #endif
-                        t += 2;
-                        steps++;
-                    }
+                    t += 2;
+                    steps++;
                 }
             }
-            if (XL) { // query.h:299,322
-                const bool ended = done >= 0;
-                const uint32_t dn = (uint32_t)done;
-                if (ended && dn < H) atomicAdd(&s_hub[dn], (unsigned long long)wgt); // LDS
-                const uint32_t u = dn - H, blk = u >> 6;
-                const uint32_t qd = __umulhi(blk, g.nbx_magic);                      // blk / nbx
-                const uint32_t dest = ((blk - qd * g.nbx) << BIN_SHIFT) | (qd << 6) | (u & 63u);
-                stage_emit<DG_STAGE>(d, q, st, ended && dn >= H, dest, wgt);
-            } else {
-                stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
-                pend = done >= 0;
-                if (pend) { pend_node = g.inv[done]; pend_w = wgt; }
-            }
         }
-        __syncthreads();
+        if (XL) { // query.h:299,322
+            const bool ended = done >= 0;
+            const uint32_t dn = (uint32_t)done;
+            if (ended && dn < H) atomicAdd(&s_hub[dn], (unsigned long long)wgt); // LDS
+            const uint32_t u = dn - H, blk = u >> 6;
+            const uint32_t qd = __umulhi(blk, g.nbx_magic);                      // blk / nbx
+            const uint32_t dest = ((blk - qd * g.nbx) << BIN_SHIFT) | (qd << 6) | (u & 63u);
+            stage_emit<DG_STAGE>(d, q, st, ended && dn >= H, dest, wgt);
+        } else {
+            stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
+            pend = done >= 0;
+            if (pend) { pend_node = g.inv[done]; pend_w = wgt; }
+        }
     }
     if (!XL) stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
     if (st.count) stage_flush<DG_STAGE>(d, q, st);
