@@ -553,8 +553,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         uint64_t rsv_add, dang;
                         const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
                         if (logi < a.rlog_cap) { rlog_val[logi] = direct ? 0ull : rsv_add; rlog_id[logi] = direct ? (uint16_t)0 : (uint16_t)l; } // algo.h:986-989, see TeamDev::rlog_id (the spare id's pop leaves an empty entry)
-                        if (!direct) {}
-                        else if (rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else { rsvl[l] = rsv_old + rsv_add; s_rsvovf = 1u; } } // (this member owns the node)
+                        if (direct && rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else { rsvl[l] = rsv_old + rsv_add; s_rsvovf = 1u; } } // (this member owns the node)
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
                         ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
                         cnt = inc ? deg : 0u;

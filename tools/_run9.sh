@@ -1,2 +1,6 @@
-timeout 900 python3 -m pytest tests/test_hip_parity_gpu.py tests/test_edge_cases_gpu.py -x -q -m gpu -k "walk or query or topk or index" 2>&1 | tail -2
-python3 tools/pushbench.py --reps 3 --mode query | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print({k:d[k] for k in ('walk_ms','walk_alloc_ms','walk_accum_ms','push_ms','batch_ms','walks_per_q')})"
+python3 tools/pushbench.py --reps 2 --graph livejournal --queries 143 variants/lib_stamps.so | python3 -c "
+import sys,json
+for l in sys.stdin:
+    try: d=json.loads(l)
+    except Exception: print(l[:500]); continue
+    print({k:d.get(k) for k in ('bin_ms','accum_ms','tail_ms','push_ms','launches','stamps_bin_Mcyc','stamps_acc_Mcyc','relax_per_q','pops_per_q')})"
