@@ -374,7 +374,7 @@ def test_topk_argument_checks(engine, oracle, tiny):
 
 @pytest.mark.parametrize("mode", ["direct", "bucketed", "bucketed_overflow", "bucketed_wide", "bucketed_wide_overflow",
                                   "bucketed_wide_multipass", "bucketed_wide_multipass_unsorted",
-                                  "bucketed_wide_multipass_nosplit", "tail_early", "tail_wide_multipass"])
+                                  "bucketed_wide_multipass_nosplit", "tail_early", "tail_early_nohubs", "tail_wide_multipass"])
 def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkeypatch):
     """The two push organisations (one global atomic per edge; LDS-bucketed) and the bucket
     overflow fallback all give the twin's bits (integer adds commute)."""
@@ -397,6 +397,8 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.set_option("team", 0)  # the team push has its own test (test_team_push_bit_exact)
     if mode.startswith("tail"):
         engine.set_option("tail_always", 1)
+    if mode == "tail_early_nohubs":  # k_push_tail with every relaxation as an atomic (default: hub increments summed in LDS)
+        engine.set_option("tail_hubs", 0)
     if mode == "tail_wide_multipass":
         mode = "bucketed_wide_multipass"
     if mode == "direct":
