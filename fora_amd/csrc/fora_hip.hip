@@ -35,7 +35,7 @@ struct Tunables {
     int64_t no_split = 0;        // 1: multi-pass graphs without the row-sorted copy / split offsets (tests)
     int64_t no_compact = 0;      // 1: no bit-packed walk copy (set_graph)
     int64_t walk_dg = 2;         // online walks over the degree-grouped copy (k_walk_dg): 0 never, 1 with one gather per walk for the endpoint's id, 2 results in bucket order; read by set_graph and at launch
-    int64_t hubs = 1024;         // narrow layout: increments for the `hubs` nodes of largest in-degree are summed per workgroup in LDS (Dev::col_hub); 0: off; read by set_graph.  ws, push of 1000 queries: 0 -> 79.5 ms, 1024 -> 75.6, 2048 -> 83.2, 4096 -> 90.5 (the LDS table costs the bin kernel its occupancy; the accumulate is bound by its sweep, not by its messages)
+    int64_t hubs = -1;           // (-1: 1024, or 4096 when the team push is this graph's default -- then the bin kernel does not run and the only reader of the hub copy is k_push_tail: 5.48 -> 4.89 ms per 1000 ws queries) narrow layout: increments for the `hubs` nodes of largest in-degree are summed per workgroup in LDS (Dev::col_hub); 0: off; read by set_graph.  ws, push of 1000 queries: 0 -> 79.5 ms, 1024 -> 75.6, 2048 -> 83.2, 4096 -> 90.5 (the LDS table costs the bin kernel its occupancy; the accumulate is bound by its sweep, not by its messages)
     int64_t hubs_wide = -1;      // the same for graphs that run the wide layout in one pass per level; -1: 2048 up to 2^28 edges, else 0 (off); read by set_graph.
                                  // LJ-sized push of 280 queries: 0 -> 560.8 ms, 1024 -> 558.7, 2048 -> 550.6, 4096 -> 681.6; Twitter-2010-sized: no gain (the top 2048 of 41.6 M nodes receive few of the edges)
     int64_t hub_min = 4096;      // ... in levels whose frontier holds at least this many nodes of the slot
@@ -1453,7 +1453,8 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     // wide kernel, 32 KB in the 1024-thread one (its stage of 12 edges per thread takes 122 of the 160 KB)
     const uint64_t nbins_all = bins_of(c);
     const int64_t lds_cap = !want_wide(c) ? 6144 : nbins_all > (uint64_t)MAX_BINS_WIDE ? 4096 : 6144;
-    const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : c->opt_.hubs, 0), lds_cap);
+    const int64_t narrow_auto = want_team(c) ? 4096 : 1024;
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : (c->opt_.hubs < 0 ? narrow_auto : c->opt_.hubs), 0), lds_cap);
     if (want == 0 || nnz == 0 || c->opt_.direct == 1) return FORA_OK;
     if (want_wide(c) && (int64_t)nbins_all > (int64_t)want_pass_bins(c, (int)nbins_all)) return FORA_OK; // several bin passes per level: the passes read the row-sorted copy, hubs are never used (make_dev)
     std::vector<uint32_t> indeg((size_t)n, 0);
