@@ -186,6 +186,7 @@ struct fora_ctx {
     uint64_t bin_launches = 0;       // parity picks the counter set
     uint32_t *h_flc = nullptr; // pinned ring of per-slot frontier sizes
     uint64_t *d_ppr2 = nullptr, *d_cursor = nullptr; // top-k: per-round ppr, index cursors (rw_counter)
+    uint32_t cursor_epoch = 0;       // batch serial number stamped into the cursor words (k_walk_alloc): 0 = the slabs hold no valid word
     uint8_t *d_active = nullptr;
     unsigned long long *d_above = nullptr;
     double *d_sel_thr = nullptr; // [B] launch_select: per-slot limit of the entries that can be among the top k
@@ -262,7 +263,7 @@ void free_index(fora_ctx *c) {
 void free_workspace(fora_ctx *c) {
     dfree(c->d_residue); dfree(c->d_ppr); dfree(c->d_wl[0]); dfree(c->d_wl[1]); dfree(c->d_scratch);
     dfree(c->d_counters); dfree(c->d_qs); dfree(c->d_src); dfree(c->d_err);
-    dfree(c->d_ppr2); dfree(c->d_cursor); dfree(c->d_active); dfree(c->d_above); dfree(c->d_sel_thr); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
+    dfree(c->d_ppr2); dfree(c->d_cursor); c->cursor_epoch = 0; dfree(c->d_active); dfree(c->d_above); dfree(c->d_sel_thr); dfree(c->d_topk_ids); dfree(c->d_topk_sc);
     dfree(c->d_upper); dfree(c->d_lower); dfree(c->d_filter); dfree(c->d_fail); dfree(c->d_round_walks);
     dfree(c->d_lb_sc); dfree(c->d_lb_ids); c->lb_cap = 0;
     dfree(c->d_nz_counts);
@@ -1134,7 +1135,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
         const uint32_t chunks = slab_grid_x(c, nq);
         h = ev_begin(c, 2);
         hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
-                           (const uint8_t *)nullptr, (uint64_t *)nullptr, (unsigned long long *)nullptr);
+                           (const uint8_t *)nullptr, (uint64_t *)nullptr, (unsigned long long *)nullptr, 0u);
         ev_end(c, h);
         launch_walks(c, d, nq, with_idx, 0u, c->opt ? 1 : 0);
     }
@@ -1892,6 +1893,17 @@ int fora_hip_walks(fora_ctx *c, uint32_t stream_id, uint32_t round, int no_zero_
 // are in the same round, so delta / rmax / omega are uniform per round; finished slots drop out.
 static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
                            int with_idx, int32_t *ids, double *scores, int32_t *rounds);
+// The index cursors of a new batch all read as zero: a new epoch (the slabs themselves are cleared when they are allocated
+// and when the 24-bit epoch wraps).
+static int next_cursor_epoch(fora_ctx *c) {
+    if (c->cursor_epoch == 0 || c->cursor_epoch >= 0xFFFFFFu) {
+        HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (uint64_t)c->B * (uint64_t)c->n * 8, c->stream));
+        c->cursor_epoch = 0;
+    }
+    c->cursor_epoch++;
+    return FORA_OK;
+}
+
 int fora_hip_topk_batch(fora_ctx *c, const int32_t *sources, int nq, int k, double epsilon, double rmax_scale,
                         int with_idx, int32_t *ids, double *scores, int32_t *rounds) {
     return with_bucket_retry(c, [&] { return topk_batch_impl(c, sources, nq, k, epsilon, rmax_scale, with_idx, ids, scores, rounds); });
@@ -1948,7 +1960,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
         const int hb = ev_begin(c, 5);
         rc = reset_batch_state(c, nb, sources + b0);
         if (rc) return rc;
-        if (with_idx) HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (uint64_t)nb * n * 8, c->stream)); // query.h:997-998
+        if (with_idx) { int rce = next_cursor_epoch(c); if (rce) return rce; } // query.h:997-998: every cursor of the batch reads as 0
         Dev d = make_dev(c, nb, with_idx != 0);
         hipLaunchKernelGGL(k_init_batch, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
         active.assign((size_t)nb, 1);
@@ -1992,7 +2004,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             dw.ppr = c->d_ppr2;
             h = ev_begin(c, 2);
             hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
-                               (const uint8_t *)c->d_active, c->d_cursor, (unsigned long long *)nullptr);
+                               (const uint8_t *)c->d_active, c->d_cursor, (unsigned long long *)nullptr, c->cursor_epoch);
             ev_end(c, h);
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, with_idx ? 1 : 0);
             const double T = (1 + epsilon) * delta; // query.h:1030
@@ -2110,7 +2122,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
         const int hb = ev_begin(c, 5);
         rc = reset_batch_state(c, nb, sources + b0);
         if (rc) return rc;
-        if (with_idx) HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, (uint64_t)nb * n * 8, c->stream)); // query.h:937-938
+        if (with_idx) { int rce = next_cursor_epoch(c); if (rce) return rce; } // query.h:937-938: every cursor of the batch reads as 0
         hipLaunchKernelGGL(k_bounds_reset, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_upper, c->d_lower); // :941-942
         Dev d = make_dev(c, nb, with_idx != 0);
         hipLaunchKernelGGL(k_init_batch, dim3((nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, d, 1);
@@ -2154,7 +2166,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
             dw.ppr = c->d_ppr2;
             h = ev_begin(c, 2);
             hipLaunchKernelGGL(k_walk_alloc<ALLOC_BOUND>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
-                               (const uint8_t *)c->d_active, c->d_cursor, c->d_round_walks);
+                               (const uint8_t *)c->d_active, c->d_cursor, c->d_round_walks, c->cursor_epoch);
             ev_end(c, h);
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, 0);
             h = ev_begin(c, 4);

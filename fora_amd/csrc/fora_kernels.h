@@ -1642,7 +1642,7 @@ __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
 enum { ALLOC_QUERY = 0, ALLOC_TOPK = 1, ALLOC_BOUND = 2 };
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const uint8_t *active,
-                                                      uint64_t *cursor, unsigned long long *round_walks) {
+                                                      uint64_t *cursor, unsigned long long *round_walks, uint32_t epoch) {
     const int q = blockIdx.y;
     const int lane = threadIdx.x & 63;
     if (MODE != ALLOC_QUERY && !active[q]) return;
@@ -1702,10 +1702,13 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                         const uint64_t icnt = d.idx_cnt[v];
                         ipos[u] = d.idx_off[v];
                         if (MODE != ALLOC_QUERY) { // query.h:575-603 / :668-709
-                            const uint64_t used = cursor[slab + v];
+                            // a cursor word carries the batch that wrote it (epoch << 40): words of earlier batches read as 0, so
+                            // the slabs are not cleared per batch (query.h:997-998; 2.3 GB per batch of 7 Twitter-2010-sized slots)
+                            const uint64_t cw = cursor[slab + v];
+                            const uint64_t used = (uint32_t)(cw >> 40) == epoch ? (cw & ((1ull << 40) - 1)) : 0ull;
                             iav[u] = icnt - used;
                             if (iav[u] > num[u]) iav[u] = num[u];
-                            cursor[slab + v] = used + iav[u];
+                            cursor[slab + v] = ((uint64_t)epoch << 40) | (used + iav[u]);
                             ipos[u] += used;
                         } else {
                             iav[u] = num[u] < icnt ? num[u] : icnt;
