@@ -87,8 +87,7 @@ struct TeamDev {
     const uint32_t *l2n;           // [T][R] node of a local id (TEAM_EMPTY: unused id)
     const uint16_t *deg16;         // [T][R] its out-degree, saturating at 0xFFFF (then Dev::deg has it)
     const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first edge << 32: one load per pop, by LOCAL id
-    uint64_t *rsvl;                // [nteams][T][R] reserve a member's nodes collect during the slot's push, by local id (all zero between slots): with
-                                   // the row word above a pop is ONE round trip of two coalesced loads -- through l2n and the slot's slab it was two dependent ones
+    uint64_t *rsvl;                // [nteams][T][R] reserve accumulators by local id (all zero between slots) for the pops that do not fit the member's log below
     // Reserve LOG: a pop's reserve (algo.h:986-989) is not added to the node's accumulator when it happens (a load and a
     // store of a random 8-byte word per pop: a fifth of the kernel's L2 requests) -- the member appends (local id, amount) to
     // its log of the slot with two coalesced stores, and at the hand-over, when its LDS no longer holds the residue, replays
@@ -104,7 +103,7 @@ struct TeamDev {
     const uint32_t *off;           // [T * T + 1] first message slot of bucket (s -> d) at [s * T + d]; [T * T]: slots per (team, parity)
     uint32_t *msg;                 // [nteams][2][off[T * T]]
     uint64_t *inct;                // [nteams][2][T][R + 64 + H] increment tables: entry e of member s = the increment of its e-th pop of the level; behind the pops: the dangling mass, then the hub sums
-    unsigned long long *cntw;      // [nteams][2][T * T] the barrier words, [destination][source]: messages in bucket (s -> d) this level (24 bits) | s's pops << 24 | barrier tag << 40; zero at launch
+    unsigned long long *cntw;      // [nteams][2][T * T] the members' words of a level, [destination][source]: messages in bucket (s -> d) (24 bits) | s's pops << 24 | level tag << 40; zero at launch
     unsigned long long *sync;      // [nteams][5][16] the fifth 128-byte line: the members' XCD census (the others: unused)
     uint32_t *slot_seq;            // [nteams][nq + 2] slot taken by the team in its k-th turn (TEAM_EMPTY: not yet)
     uint32_t *ctl;                 // [0] next slot, [32] abort flag
