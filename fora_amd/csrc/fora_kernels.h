@@ -2657,6 +2657,10 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     static_assert(WT >= 1 && WT <= 64, "a lane loads one item of its wave's tile");
     __shared__ uint64_t w_j0[NW][WT], w_incr[NW][WT], w_rem[NW][WT];
     __shared__ uint32_t w_v[NW][WT], w_vp[NW][WT], w_idxn[NW][WT], w_pref[NW][WT + 1], s_w[NW];
+    // A fifth of all walks stop where they started (algo.h:131-133 at the first step): with XL their weights are summed per
+    // item in LDS (w_self) and leave as ONE result per item when the wave replaces its tile -- a walk that outlives its tile
+    // (its tag names the tile it came from) is emitted on its own as before.
+    __shared__ unsigned long long w_self[XL ? NW : 1][XL ? WT : 1];
     const int q = blockIdx.y;
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
     if (!nitems || *d.err) return;
@@ -2692,6 +2696,21 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     bool pend = false;
     uint32_t pend_node = 0;
     uint64_t pend_w = 0;
+    unsigned long long *s_self = w_self[XL ? wid : 0];
+    if (XL && lane < WT) s_self[lane] = 0;
+    uint32_t gen = 0, tag = 0; // tiles this wave has loaded; (tile << 6 | item) of this lane's walk
+    // the tile's self sums -> results like any other endpoint (hub accumulators / the wave's stage), then zero
+    auto flush_self = [&]() {
+        if (!XL) return;
+        const unsigned long long sv = lane < WT ? s_self[lane] : 0ull;
+        const uint32_t dn = lane < WT ? w_vp[wid][lane] : 0u;
+        if (lane < WT && sv) s_self[lane] = 0;
+        if (sv && dn < H) atomicAdd(&s_hub[dn], sv); // LDS
+        const uint32_t u = dn - H, blk = u >> 6;
+        const uint32_t qd = __umulhi(blk, g.nbx_magic);
+        const uint32_t dest = ((blk - qd * g.nbx) << BIN_SHIFT) | (qd << 6) | (u & 63u);
+        stage_emit<DG_STAGE>(d, q, st, sv != 0 && dn >= H, dest, (uint64_t)sv);
+    };
     uint64_t *s_j0 = w_j0[wid], *s_incr = w_incr[wid], *s_rem = w_rem[wid];
     uint32_t *s_v = w_v[wid], *s_vp = w_vp[wid], *s_idxn = w_idxn[wid], *s_pref = w_pref[wid];
     const uint32_t ntiles = (nitems + WT - 1) / WT;
@@ -2707,6 +2726,8 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
         const unsigned long long idle = __ballot(!active);
         if (idle && wptr == wend) { // lanes are free and the tile is handed out: the next tile that has walks
             while (wptr == wend && tile < ntiles) {
+                if (gen) flush_self();
+                gen++;
                 const uint32_t i = tile * WT + lane;
                 uint32_t cnt = 0;
                 if (lane < WT && i < nitems) {
@@ -2752,6 +2773,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                 wgt = s_incr[item] + (wj < s_rem[item] ? 1 : 0); // (!XL: the lane's previous result already waits in pend_w)
                 cur = startp;
                 t = 0;
+                tag = (gen << 6) | item;
                 if (startp >= g.zero_first) done = (int32_t)startp; // algo.h:127-129
                 else active = true;
             }
@@ -2793,8 +2815,12 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
         if (XL) { // query.h:299,322
-            const bool ended = done >= 0;
+            bool ended = done >= 0;
             const uint32_t dn = (uint32_t)done;
+            if (ended && dn == startp && (tag >> 6) == gen) { // back where it started, and the item is still in the tile
+                atomicAdd(&s_self[tag & 63u], (unsigned long long)wgt); // LDS
+                ended = false;
+            }
             if (ended && dn < H) atomicAdd(&s_hub[dn], (unsigned long long)wgt); // LDS
             const uint32_t u = dn - H, blk = u >> 6;
             const uint32_t qd = __umulhi(blk, g.nbx_magic);                      // blk / nbx
@@ -2807,6 +2833,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
     if (!XL) stage_emit<DG_STAGE>(d, q, st, pend, pend_node, pend_w);
+    if (gen) flush_self();
     if (st.count) stage_flush<DG_STAGE>(d, q, st);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)d.nbins; i += DG_THREADS) bkc[(uint64_t)i * d.sub] = st.fill[i];
