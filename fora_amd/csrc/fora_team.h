@@ -151,8 +151,14 @@ __device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE 
 #define FORA_TEAM_HEAVY 1024
 #endif
 constexpr uint32_t TEAM_HEAVY = FORA_TEAM_HEAVY; // rows of more edges are relaxed by the whole workgroup, consecutive lanes on consecutive edges
-constexpr int TEAM_NHEAVY = 128;
-constexpr int TEAM_MAXGROUPS = 256;   // 64-id groups of a member at most, the spare id's included
+#ifndef FORA_TEAM_NHEAVY
+#define FORA_TEAM_NHEAVY 128
+#endif
+#ifndef FORA_TEAM_MAXGROUPS
+#define FORA_TEAM_MAXGROUPS 256
+#endif
+constexpr int TEAM_NHEAVY = FORA_TEAM_NHEAVY;       // heavy rows of a level a member can share out (the others stay with the wave that popped them)
+constexpr int TEAM_MAXGROUPS = FORA_TEAM_MAXGROUPS; // 64-id groups of a member at most, the spare id's included
 
 // word[k] / dst[k]: this lane's messages of a chunk (dst TEAM_EMPTY: none).  s_fill[d]: the next free slot of my bucket
 // (me -> d) in the level's message buffer -- one returning LDS add per message; all four in flight together, then the stores.
