@@ -13,7 +13,7 @@ STREAM_INDEX = 0xFFFFFFFF
 SYMBOLS = [
     "fora_hip_create", "fora_hip_destroy", "fora_hip_device_count", "fora_hip_last_error", "fora_hip_device_info",
     "fora_hip_set_graph", "fora_hip_set_params", "fora_hip_set_params_raw", "fora_hip_get_params",
-    "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_set_option", "fora_hip_set_balanced", "fora_hip_index_sizes", "fora_hip_build_index",
+    "fora_hip_set_batch", "fora_hip_get_batch", "fora_hip_set_option", "fora_hip_get_option", "fora_hip_set_balanced", "fora_hip_index_sizes", "fora_hip_build_index",
     "fora_hip_get_index", "fora_hip_set_index", "fora_hip_clear_index", "fora_hip_query_batch",
     "fora_hip_query_batch_fix", "fora_hip_topk_batch", "fora_hip_topk_bound_batch", "fora_hip_power_iteration_batch", "fora_hip_push_batch", "fora_hip_walk_counts",
     "fora_hip_walks", "fora_hip_reset_timing", "fora_hip_get_timing", "fora_hip_get_stamps",
@@ -258,6 +258,11 @@ class Engine:
     # ---- measurement
     def set_option(self, name, value):
         self._chk(self._lib.fora_hip_set_option(self._ctx, name.encode(), C.c_int64(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._chk(self._lib.fora_hip_get_option(self._ctx, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def reset_options(self):
         self._chk(self._lib.fora_hip_set_option(self._ctx, b"reset", C.c_int64(0)))

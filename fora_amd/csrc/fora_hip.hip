@@ -64,6 +64,8 @@ struct Tunables {
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
     int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
+    int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
+    int64_t team_coop = -1;      // k_push_team launch: 1 hipLaunchCooperativeKernel (all workgroups co-resident or the launch fails; cooperative kernels of different contexts do not interleave), 0 plain launch behind an occupancy check, -1: cooperative when the device reports support
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -73,7 +75,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -138,8 +140,13 @@ struct fora_ctx {
     unsigned long long *d_team_cnt = nullptr; // the teams' barrier words (TeamDev::cntw)
     uint32_t *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
     uint32_t team_n = 0;             // teams of a launch
-    bool team_attr = false;          // dynamic LDS limit of k_push_team raised
     bool team_dirty = false;         // a launch ended with an error flag: its reserve accumulators (TeamDev::rsvl) may not be zero
+    bool team_timeout_seen = false;  // the last device error was ERR_TEAM_TIMEOUT (with_retry runs the call again without the team push)
+    int team_suspend = 0;            // calls left that push with the bucketed kernels after a team time-out
+    uint64_t team_fallbacks = 0;     // calls re-run that way so far (fora_hip_get_option "team_fallbacks")
+    int team_fit = -1;               // 1: every workgroup of a k_push_team launch fits the device at once (occupancy x CUs >= grid); 0: no team push; -1: not asked yet
+    bool team_coop_ok = false;       // launch k_push_team cooperatively (option team_coop, device attribute)
+    bool team_coop_failed = false;   // hipLaunchCooperativeKernel refused once: plain launches from then on
 
     // params
     bool have_params = false;
@@ -271,7 +278,7 @@ void free_workspace(fora_ctx *c) {
     dfree(c->d_fl[0]); dfree(c->d_fl[1]); dfree(c->d_fl_count); dfree(c->d_inc_tab[0]); dfree(c->d_inc_tab[1]); dfree(c->d_ov_w); dfree(c->d_ov_inc); dfree(c->d_ov_count); dfree(c->d_ov_bin);
     dfree(c->d_bk_w); dfree(c->d_bk_inc); dfree(c->d_bk_count); dfree(c->d_wit_count); dfree(c->d_sw); dfree(c->d_tile_ctr);
     dfree(c->d_dbm); dfree(c->d_dflag); dfree(c->d_dl); dfree(c->d_hubsum);
-    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_rsvl); dfree(c->d_team_rlog_id); dfree(c->d_team_rlog_val); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0;
+    dfree(c->d_team_msg); dfree(c->d_team_inct); dfree(c->d_team_rsvl); dfree(c->d_team_rlog_id); dfree(c->d_team_rlog_val); dfree(c->d_team_cnt); dfree(c->d_team_ctl); c->team_n = 0; c->team_fit = -1;
     if (c->h_flc) (void)hipHostFree(c->h_flc);
     c->h_flc = nullptr;
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -419,7 +426,7 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 // the `team` / `team_size` options ask for another shape.
 static bool want_team(const fora_ctx *c) {
     const bool on = c->opt_.team == 1 || (c->opt_.team < 0 && c->dangling_frac <= 0.2);
-    return on && want_binned(c) && !want_wide(c) && c->nnz > 0;
+    return on && want_binned(c) && !want_wide(c) && c->nnz > 0 && c->nnz < (1ll << 32); // (rowl / colt / off index edges with 32 bits)
 }
 int ensure_team(fora_ctx *c) {
     if (c->is_twin) return FORA_OK; // shares the first lane's tables (sync_twin)
@@ -516,6 +523,7 @@ int ensure_team(fora_ctx *c) {
     return FORA_OK;
 }
 
+int team_fits(fora_ctx *c);
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     if (int rt = ensure_team(c)) return rt;
@@ -544,6 +552,11 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         size_t fr = 0, tot = 0;
         HIPCHK(c, hipMemGetInfo(&fr, &tot));
         uint64_t budget = (uint64_t)(fr * (c->opt_.pipeline == 1 ? 0.4 : 0.75)); // with option pipeline a second lane holds its own workspace
+        if (c->team_T) { // the team push's own buffers (allocated below) come out of the same memory
+            const uint64_t T = c->team_T, nt = std::max<uint64_t>(1, (uint64_t)c->prop.multiProcessorCount * TEAM_WGS_PER_CU / T);
+            const uint64_t team_bytes = nt * (2 * c->team_cap * 4 + 3 * T * (c->team_R + 64 + c->team_H) * 8 + T * (10ull << 17) + 2 * T * T * 8);
+            budget -= std::min<uint64_t>(budget / 2, team_bytes);
+        }
         B = (int)std::min<uint64_t>(1024, std::max<uint64_t>(1, budget / p.per_slot)); // ws, 1000 queries: 2845 q/s at 256, 3035 at 512, 3101 at 1000
     }
     B = std::max(1, B);
@@ -582,18 +595,24 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             if (c->opt_.team_max > 0) nteams = std::min<uint32_t>(nteams, (uint32_t)c->opt_.team_max);
             size_t fr = 0, tot = 0;
             HIPCHK(c, hipMemGetInfo(&fr, &tot));
-            const uint64_t per_team = 2 * c->team_cap * 4 + 3 * (uint64_t)T * (c->team_R + 64 + c->team_H) * 8;
+            // pops of one member in one slot (ws-sized graph at eps 0.5: 43 k on average); beyond it: rsvl.  Tight memory: shorter logs
+            c->team_rlog_cap = 1u << 17;
+            auto per_team_bytes = [&](uint32_t logcap) { // message buffers + increment tables (two parities), rsvl, reserve logs, words
+                return 2 * c->team_cap * 4 + 3 * (uint64_t)T * (c->team_R + 64 + c->team_H) * 8 + (uint64_t)T * logcap * 10 + 2 * (uint64_t)T * T * 8;
+            };
+            while (c->team_rlog_cap > 1024 && per_team_bytes(c->team_rlog_cap) > fr / 4) c->team_rlog_cap /= 2;
+            const uint64_t per_team = per_team_bytes(c->team_rlog_cap);
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
             HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
-            c->team_rlog_cap = 1u << 17; // pops of one member in one slot (ws-sized graph at eps 0.5: 43 k on average); beyond it: rsvl
             HIPCHK(c, hipMalloc(&c->d_team_rlog_id, (size_t)nteams * T * c->team_rlog_cap * 2));
             HIPCHK(c, hipMalloc(&c->d_team_rlog_val, (size_t)nteams * T * c->team_rlog_cap * 8));
             HIPCHK(c, hipMalloc(&c->d_team_cnt, (size_t)nteams * 2 * T * T * 8));
             HIPCHK(c, hipMalloc(&c->d_team_ctl, (64 + (size_t)nteams * 5 * 16 * 2 + (size_t)nteams * ((size_t)B + 2)) * 4));
             c->team_n = nteams;
+            if (int rf = team_fits(c)) return rf;
         }
     } else {
         HIPCHK(c, hipMalloc(&c->d_wl[0], slab * 8));
@@ -723,11 +742,12 @@ int check_dev_err(fora_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->bucket_overflow = (e & ERR_BUCKET_OVERFLOW) != 0;
+    c->team_timeout_seen = (e & ERR_TEAM_TIMEOUT) != 0;
     if (e) c->team_dirty = true;
     if (e) {
         char buf[256];
         snprintf(buf, sizeof(buf), "device work list overflow (flags 0x%x%s)", e,
-                 (e & ERR_TEAM_TIMEOUT) ? ": a team of k_push_team waited 3 s for a member (workgroups not co-resident?); FORA_HIP_TEAM=0 selects the bucketed push"
+                 (e & ERR_TEAM_TIMEOUT) ? ": a team of k_push_team waited too long for a member (workgroups not co-resident); the call is run again with the bucketed push"
                  : (e & ERR_BUCKET_OVERFLOW) ? ": message buckets and their overflow list are full, raise FORA_HIP_BKCAP" : "");
         return fail(c, FORA_E_OVERFLOW, buf);
     }
@@ -886,7 +906,26 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
 // Team push of a batch (fora_team.h): ONE launch runs every slot's push down to a small frontier with the residue
 // resident in LDS, k_push_tail finishes the slots.  Nothing here waits for the device.
 static bool use_team(const fora_ctx *c, const Dev &d) {
-    return c->team_T && c->d_team_msg && c->binned && !d.wide && !c->balanced && d.rounds <= 1 && d.defer_k == 0 && want_team(c);
+    // not while a second lane may have its own full-chip team kernel in flight (option pipeline), not after a time-out
+    return c->team_T && c->d_team_msg && c->binned && !d.wide && !c->balanced && d.rounds <= 1 && d.defer_k == 0 && want_team(c) &&
+           c->team_fit != 0 && c->team_suspend == 0 && c->opt_.pipeline != 1 && !c->is_twin;
+}
+// Can every workgroup of a k_push_team launch be resident at once?  (Asked once per workspace; raises the kernel's
+// dynamic LDS limit on the way.)
+int team_fits(fora_ctx *c) {
+    if (c->team_fit >= 0 || !c->team_T || !c->d_team_msg) return FORA_OK;
+    const size_t lds = ((size_t)c->team_R + 1 + c->team_H) * 8;
+    hipFuncAttributes fa{};
+    HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)k_push_team));
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(163840 - (int)fa.sharedSizeBytes)));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_push_team, TEAM_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    const uint32_t grid = c->team_n * c->team_T;
+    c->team_fit = (uint64_t)per_cu * (uint64_t)c->prop.multiProcessorCount >= grid ? 1 : 0;
+    int coop = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess) { (void)hipGetLastError(); coop = 0; }
+    c->team_coop_ok = c->opt_.team_coop == 1 || (c->opt_.team_coop < 0 && coop != 0);
+    return FORA_OK;
 }
 int run_push_team(fora_ctx *c, const Dev &d) {
     const uint32_t T = c->team_T, nteams = c->team_n;
@@ -907,20 +946,25 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     const uint32_t grid = nteams * T;
     a.xcd = (c->opt_.team_xcd >= 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? (uint32_t)c->opt_.team_xcd : 0u;
     a.stamps = c->d_stamps;
-    a.timeout_ticks = 300000000ull; // 3 s of the 100 MHz wall clock
+    a.timeout_ticks = (uint64_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_timeout_ms, 0), 60000) * 100000ull; // (100 MHz wall clock)
     const size_t lds = ((size_t)a.R + 1 + a.H) * 8;
-    if (!c->team_attr) { // dynamic LDS up to what the static arrays leave of the CU's 160 KiB
-        hipFuncAttributes fa{};
-        HIPCHK(c, hipFuncGetAttributes(&fa, (const void *)k_push_team));
-        HIPCHK(c, hipFuncSetAttribute((const void *)k_push_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(163840 - (int)fa.sharedSizeBytes)));
-        c->team_attr = true;
-    }
     if (c->team_dirty) { HIPCHK(c, hipMemsetAsync(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8, c->stream)); c->team_dirty = false; }
     HIPCHK(c, hipMemsetAsync(c->d_team_ctl, 0, (64 + (size_t)nteams * 5 * 16 * 2) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_team_cnt, 0, (size_t)nteams * 2 * T * T * 8, c->stream)); // no barrier tag of an earlier launch
     HIPCHK(c, hipMemsetAsync(a.slot_seq, 0xFF, (size_t)nteams * ((size_t)d.nq + 2) * 4, c->stream));
     int h = ev_begin(c, 10);
-    hipLaunchKernelGGL(k_push_team, dim3(grid), dim3(TEAM_THREADS), lds, c->stream, a);
+    // The members of a team spin on each other: every workgroup of the launch must be resident at once.  team_fits() has
+    // checked that the grid fits the device; a cooperative launch makes the runtime promise it (and keeps cooperative
+    // kernels of other contexts from interleaving their workgroups with ours).  Whatever still goes wrong ends in
+    // ERR_TEAM_TIMEOUT after team_timeout_ms, and with_retry runs the call again through the bucketed kernels.
+    bool launched = false;
+    if (c->team_coop_ok && !c->team_coop_failed) {
+        void *args[] = {(void *)&a};
+        const hipError_t le = hipLaunchCooperativeKernel((const void *)k_push_team, dim3(grid), dim3(TEAM_THREADS), args, (unsigned)lds, c->stream);
+        if (le == hipSuccess) launched = true;
+        else { (void)hipGetLastError(); c->team_coop_failed = true; }
+    }
+    if (!launched) hipLaunchKernelGGL(k_push_team, dim3(grid), dim3(TEAM_THREADS), lds, c->stream, a);
     ev_end(c, h);
     c->timing.levels++;
     if (a.tail_max) {
@@ -1322,13 +1366,30 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
 
 } // namespace
 
-// A batch whose message buckets (and their overflow list) were too small is not a caller error: double the bucket
-// capacity, re-plan the workspace and run the call again from scratch (results never depend on the capacity).
+// Two device conditions are not caller errors and are answered by running the call again from scratch (results never
+// depend on either): message buckets (and their overflow list) too small -- double the bucket capacity and re-plan the
+// workspace; a team of k_push_team that waited too long for a member (its workgroups were not co-resident: another
+// context's kernels held CUs) -- the next calls push with the bucketed kernels.
+constexpr int TEAM_SUSPEND_CALLS = 8;
 template <class F> int with_bucket_retry(fora_ctx *c, F call) {
     const uint32_t scale0 = c ? c->bk_scale : 1;
+    bool team_retried = false;
+    auto forget_attempt = [&](const fora_timing &t0) { // the failed attempt must leave no trace in the timings: drop its event pairs and counters
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        c->ev_used = 0;
+        c->timing = t0;
+        c->pending_nq = 0;
+        if (c->twin) {
+            (void)hipStreamSynchronize(c->twin->stream);
+            c->twin->ev_used = 0;
+            c->twin->pending_nq = 0;
+        }
+    };
     for (;;) {
         const fora_timing t0 = c ? c->timing : fora_timing{};
         const int rc = call();
+        if (c && rc == FORA_OK && c->team_suspend > 0 && !team_retried) c->team_suspend--; // (a retried call has just started the count)
         if (!c || rc != FORA_E_OVERFLOW) {
             if (c && rc != FORA_OK && c->bk_scale != scale0) { // the enlarged plan did not help: do not keep it
                 c->bk_scale = scale0;
@@ -1337,6 +1398,14 @@ template <class F> int with_bucket_retry(fora_ctx *c, F call) {
                 if (c->twin) { c->twin->bk_scale = scale0; free_workspace(c->twin); }
             }
             return rc;
+        }
+        if (c->team_timeout_seen && !team_retried) {
+            c->team_timeout_seen = false;
+            c->team_suspend = TEAM_SUSPEND_CALLS;
+            c->team_fallbacks++;
+            team_retried = true;
+            forget_attempt(t0);
+            continue;
         }
         const bool bucket = c->bucket_overflow || (c->twin && c->twin->bucket_overflow);
         if (!bucket || c->bk_scale >= (1u << 16)) {
@@ -1350,17 +1419,9 @@ template <class F> int with_bucket_retry(fora_ctx *c, F call) {
         }
         c->bk_scale *= 2;
         c->bucket_overflow = false;
-        // the failed attempt must leave no trace in the timings: drop its event pairs and counters
-        (void)hipSetDevice(c->device);
-        (void)hipStreamSynchronize(c->stream);
-        c->ev_used = 0;
-        c->timing = t0;
-        c->pending_nq = 0;
+        forget_attempt(t0);
         if (c->twin) {
             c->twin->bucket_overflow = false;
-            (void)hipStreamSynchronize(c->twin->stream);
-            c->twin->ev_used = 0;
-            c->twin->pending_nq = 0;
             c->twin->bk_scale = c->bk_scale;
         }
         free_workspace(c);
@@ -1703,6 +1764,7 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
         free_workspace(c);
         if (c->twin) free_workspace(c->twin);
         c->opt_ = tunables_from_env();
+        c->team_suspend = 0; // (a time-out's back-off too)
         c->profiling = c->opt_.profile != 0;
         c->grid_blocks = c->opt_.grid > 0 ? (int)c->opt_.grid : 2048;
         if (c->twin) { c->twin->opt_ = c->opt_; c->twin->grid_blocks = c->grid_blocks; }
@@ -1717,6 +1779,18 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
             if (!strcmp(name, "grid")) { c->grid_blocks = value > 0 ? (int)value : 2048; if (c->twin) c->twin->grid_blocks = c->grid_blocks; }
             return FORA_OK;
         }
+    return fail(c, FORA_E_ARG, std::string("unknown option ") + name);
+}
+
+int fora_hip_get_option(fora_ctx *c, const char *name, int64_t *value) {
+    if (!c || !name || !value) return FORA_E_ARG;
+    // read-only state of the engine beside the knobs
+    if (!strcmp(name, "team_fallbacks")) { *value = (int64_t)c->team_fallbacks; return FORA_OK; } // calls re-run with the bucketed push after a team time-out
+    if (!strcmp(name, "team_suspended")) { *value = c->team_suspend; return FORA_OK; }             // calls left that do not try the team push
+    if (!strcmp(name, "team_members")) { *value = c->team_T; return FORA_OK; }                      // 0: this graph / workspace has no team push
+    if (!strcmp(name, "team_cooperative")) { *value = c->team_coop_ok && !c->team_coop_failed ? 1 : 0; return FORA_OK; }
+    for (const auto &o : OPTIONS)
+        if (!strcmp(name, o.name)) { *value = c->opt_.*(o.field); return FORA_OK; }
     return fail(c, FORA_E_ARG, std::string("unknown option ") + name);
 }
 

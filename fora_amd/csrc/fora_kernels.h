@@ -1797,7 +1797,6 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
         __syncthreads();
     };
     for (uint32_t c0 = blockIdx.x * SLAB_UNROLL; c0 < nchunk; c0 += gridDim.x * SLAB_UNROLL) { // see k_walk_alloc
-        if (d.binned && s_cnt > FB - SLAB_UNROLL * BLOCK) flush(); // (uniform: s_cnt is stable between the barriers)
         uint64_t rr[SLAB_UNROLL];
 #pragma unroll
         for (int u = 0; u < SLAB_UNROLL; u++) {
@@ -1825,7 +1824,13 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
                 s_node[pos] = v; s_val[pos] = r;
             }
         }
+        // The flush decision must be the same in every wave (flush() holds barriers): all waves read s_cnt between two
+        // barriers, where nobody adds to it.  (Round 4 read it at the top of the next trip, where a faster wave could
+        // already have added: waves could disagree, pair their barriers wrongly and lose or duplicate entries.)
         __syncthreads();
+        const bool full = d.binned && s_cnt > FB - SLAB_UNROLL * BLOCK;
+        __syncthreads();
+        if (full) flush();
     }
     if (d.binned) flush();
 }

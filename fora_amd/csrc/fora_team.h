@@ -114,23 +114,49 @@ struct TeamDev {
     uint64_t timeout_ticks;        // wall_clock64 ticks (100 MHz) a member waits for its team before it gives up
 };
 
-__device__ __forceinline__ uint32_t team_deg(const TeamDev &a, uint64_t ri, uint32_t v) { // exact out-degree (see ri_deg)
-    const uint32_t dg = (uint32_t)ri & DEG_SAT;
-    return dg == DEG_SAT ? (uint32_t)(a.row_ptr[v + 1] - (int64_t)(ri >> 24)) : dg;
+// The kernel never keeps its argument struct in registers.  By value, the ~45 fields were loaded at the kernel's entry
+// and lived in SGPRs -- 272 of them spilled into VGPR lanes, 1035 v_readlane / v_writelane of 5975 static instructions,
+// five VGPR spills on top because those lanes occupied a kernel already at the 128-register cap (round 4's code object,
+// tools/isa_audit.py).  Instead every PHASE reads what it needs from the kernarg segment (constant address space: scalar
+// loads, cached) through a pointer it has just laundered: the loads cannot move above the laundering, so a field is live
+// from its phase's start to its last use there and no longer.
+typedef const __attribute__((address_space(4))) TeamDev *TeamArgs;
+__device__ __forceinline__ TeamArgs team_args() {
+    TeamArgs p = (TeamArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
+
+// set bits of a wave mask below this lane (v_mbcnt: two instructions, the mask in scalar registers)
+__device__ __forceinline__ uint32_t rank_below(unsigned long long mk) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+}
+// A per-thread value the optimiser must treat as new: predicates derived from it (tid < 32, lane == 0 && ...) are not
+// hoisted out of the level loop, where each lived in two scalar registers for the whole launch (130 of them spilled).
+__device__ __forceinline__ int fresh(int x) { asm volatile("" : "+v"(x)); return x; }
 
 // one poll loop for everything a member waits for: returns false when the launch is being abandoned
 template <class DONE>
-__device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE done) {
+__device__ __forceinline__ bool team_wait(DONE done) {
     const uint64_t t0 = wall_clock64();
+    {
+        const TeamArgs a = team_args();
+        if (a->timeout_ticks == 0) { // option team_timeout_ms = 0 (tests): give up at once, as if the team had waited in vain
+            __hip_atomic_store(&a->ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(a->err, ERR_TEAM_TIMEOUT);
+            return false;
+        }
+    }
     for (uint32_t it = 1;; it++) {
         if (done()) return true;
         __builtin_amdgcn_s_sleep(2);
         if ((it & 255u) == 0) {
-            if (__hip_atomic_load(&a.ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-            if (wall_clock64() - t0 > a.timeout_ticks) {
-                __hip_atomic_store(&a.ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(err, ERR_TEAM_TIMEOUT);
+            const TeamArgs a = team_args();
+            uint32_t *ctl = a->ctl;
+            if (__hip_atomic_load(&ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (wall_clock64() - t0 > a->timeout_ticks) {
+                __hip_atomic_store(&ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(a->err, ERR_TEAM_TIMEOUT);
                 return false;
             }
         }
@@ -140,7 +166,7 @@ __device__ __forceinline__ bool team_wait(const TeamDev &a, uint32_t *err, DONE 
 #ifdef FORA_STAMPS
 #define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TSTAMP(k) do { const long long n_ = clock64(); ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
-#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (ts_a_[i_]) atomicAdd(&a.stamps[i_], ts_a_[i_]); } while (0)
+#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (ts_a_[i_]) atomicAdd(&team_args()->stamps[i_], ts_a_[i_]); } while (0)
 #else
 #define TSTAMP_DECL
 #define TSTAMP(k) do {} while (0)
@@ -181,7 +207,7 @@ __device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], cons
 // Inside a level nothing but the consume -> sweep and the emit -> barrier seams is a workgroup barrier: the waves draw the
 // level's 64-id groups from a shared counter, collect the crossing nodes in a wave-private list and pop / emit them 64 at a
 // time on their own (prefix sums by wave scan), so the sixteen waves of a member overlap each other's memory round trips.
-__global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev a) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU)
+__global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU / 256) k_push_team(const TeamDev kernarg_only) { // (4 waves per SIMD: one 1024-thread or two 512-thread workgroups per CU; the argument is read through team_args())
     extern __shared__ uint64_t res[];                        // [R + 1] residue of my nodes; [R]: the slot's source when it has no local id; then [H] hub sums of the level
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
@@ -194,113 +220,124 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // next free slot of my bucket (me -> d) in the level's message buffer; its first slot
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf;
     __shared__ unsigned long long s_dang, s_acc[3];
+    (void)kernarg_only;
 
-    const uint32_t T = a.T, R = a.R;
-    const uint32_t H = a.H;
-    const uint32_t tstride = R + 64 + H; // entries of one increment table
-    unsigned long long *s_hub = (unsigned long long *)(res + R + 1); // [H]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1;
-    uint32_t team, me;
-    if (a.xcd) { // blocks b and b + 8 share an XCD (observed, not promised): a team = T blocks of one residue class
-        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3; // per: blocks per class, a multiple of T
-        team = x * (per / T) + j / T;
-        me = j % T;
-    } else {
-        team = blockIdx.x / T;
-        me = blockIdx.x % T;
-    }
-    const uint32_t nit = (R + TEAM_THREADS - 1) / TEAM_THREADS; // <= TEAM_NIT
-    const bool thr_small = (a.t1 >> 47) == 0;                    // then a 16-bit degree's threshold is two multiplies (see the sweep)
-    const uint32_t t1_lo = (uint32_t)a.t1, t1_hi = (uint32_t)(a.t1 >> 32);
-    const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
-    const uint64_t cap_total = a.off[T * T];
-    const uint32_t *l2n = a.l2n + (uint64_t)me * R;
-    const uint64_t *rowl = a.rowl + (uint64_t)me * R;
-    uint64_t *rsvl = a.rsvl + ((uint64_t)team * T + me) * R;
-    uint16_t *rlog_id = a.rlog_id + ((uint64_t)team * T + me) * a.rlog_cap;
-    uint64_t *rlog_val = a.rlog_val + ((uint64_t)team * T + me) * a.rlog_cap;
-    unsigned long long *sync = a.sync + (uint64_t)team * 5 * 16;
-    uint32_t *seq = a.slot_seq + (uint64_t)team * ((uint32_t)a.nq + 2);
-    for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
-    if (tid < TEAM_MAX) s_moff[tid] = tid < (int)T ? a.off[me * T + tid] : 0u;
-    const uint32_t coffv = (uint32_t)lane < T ? a.off[(uint32_t)lane * T + me] : 0u; // first slot of bucket (lane -> me)
+    // What stays in scalar registers for the whole launch: T, R, H, my place (team, me), the size of a message buffer.
+    uint32_t T, R, H, team, me, cap_total, coffv;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0, lane = tid & 63, wid = tid >> 6;
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
     uint32_t dgp[(TEAM_NIT + 1) / 2];
+    bool same_xcd;
+    {
+        const TeamArgs a = team_args();
+        T = a->T; R = a->R; H = a->H;
+        if (a->xcd) { // blocks b and b + 8 share an XCD (observed, not promised): a team = T blocks of one residue class
+            const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3; // per: blocks per class, a multiple of T
+            team = x * (per / T) + j / T;
+            me = j % T;
+        } else {
+            team = blockIdx.x / T;
+            me = blockIdx.x % T;
+        }
+        const uint32_t *off = a->off;
+        cap_total = off[T * T];
+        for (uint32_t l = tid; l <= R + H; l += TEAM_THREADS) res[l] = 0; // (residues and hub sums)
+        if (tid < TEAM_MAX) s_moff[tid] = tid < (int)T ? off[me * T + tid] : 0u;
+        coffv = (uint32_t)lane < T ? off[(uint32_t)lane * T + me] : 0u; // first slot of bucket (lane -> me)
+        const uint16_t *deg16 = a->deg16 + (uint64_t)me * R;
+        const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(wid) * 64u;
 #pragma unroll
-    for (int it = 0; it < TEAM_NIT; it++) {
-        const uint32_t l = it * TEAM_THREADS + tid;
-        const uint32_t dv = ((uint32_t)it < nit && l < R) ? (uint32_t)a.deg16[(uint64_t)me * R + l] : 0u;
-        if (it & 1) dgp[it >> 1] |= dv << 16; else dgp[it >> 1] = dv;
+        for (int it = 0; it < TEAM_NIT; it++) { // (R is a multiple of 64: a wave's 64 ids are all below R or none is)
+            const uint32_t l = it * TEAM_THREADS + tid;
+            const uint32_t dv = (it * TEAM_THREADS + wbase < R) ? (uint32_t)deg16[l] : 0u;
+            if (it & 1) dgp[it >> 1] |= dv << 16; else dgp[it >> 1] = dv;
+        }
+        // Do the team's members share an XCD?  Each adds 1 to the byte of its XCC id (HW_REG_XCC_ID) in the census word and
+        // waits for all T.  Members of one XCD share its L2: what a member has stored (and waited for: vmcnt(0)) is in that L2,
+        // and a load that bypasses L1 (sc1: relaxed agent-scope atomic load) sees it -- no release write-back of the L2 and no
+        // acquire invalidate per level (~1.7 us each and more with freshly dirtied lines, MI355X guide).  Otherwise: both fences.
+        if (tid == 0) {
+            s_abort = 0;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *cw = a->sync + (uint64_t)team * 5 * 16 + 4 * 16;
+            __hip_atomic_fetch_add(cw, 1ull << (8 * (xcc & 7u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long v = 0;
+            const bool ok = team_wait([&] {
+                v = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t tot = 0;
+                for (int i = 0; i < 8; i++) tot += (uint32_t)(v >> (8 * i)) & 0xFFu;
+                return tot == T;
+            });
+            bool one = false;
+            for (int i = 0; i < 8; i++) one |= ((uint32_t)(v >> (8 * i)) & 0xFFu) == T;
+            s_F = (one && a->xcd != 2) ? 1u : 0u; // (xcd == 2: tests force the fenced form)
+            s_ok = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        same_xcd = s_F != 0;
+        __syncthreads();
     }
-    // Do the team's members share an XCD?  Each adds 1 to the byte of its XCC id (HW_REG_XCC_ID) in the census word and
-    // waits for all T.  Members of one XCD share its L2: what a member has stored (and waited for: vmcnt(0)) is in that L2,
-    // and a load that bypasses L1 (sc1: relaxed agent-scope atomic load) sees it -- no release write-back of the L2 and no
-    // acquire invalidate per level (~1.7 us each and more with freshly dirtied lines, MI355X guide).  Otherwise: both fences.
-    if (tid == 0) {
-        s_abort = 0;
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *cw = &sync[4 * 16];
-        __hip_atomic_fetch_add(cw, 1ull << (8 * (xcc & 7u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long v = 0;
-        const bool ok = team_wait(a, a.err, [&] {
-            v = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t tot = 0;
-            for (int i = 0; i < 8; i++) tot += (uint32_t)(v >> (8 * i)) & 0xFFu;
-            return tot == T;
-        });
-        bool one = false;
-        for (int i = 0; i < 8; i++) one |= ((uint32_t)(v >> (8 * i)) & 0xFFu) == T;
-        s_F = (one && a.xcd != 2) ? 1u : 0u; // (xcd == 2: tests force the fenced form)
-        s_ok = ok ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_ok) return;
-    const bool same_xcd = s_F != 0;
-    __syncthreads();
+    const uint32_t nit = (R + TEAM_THREADS - 1) / TEAM_THREADS; // <= TEAM_NIT
+    const uint32_t ngroups = R / 64 + 1;                        // the last one holds the spare id R alone
+    const uint32_t tstride = R + 64 + H;                        // entries of one increment table
+    unsigned long long *s_hub = (unsigned long long *)(res + R + 1); // [H]
     TSTAMP_DECL
     uint32_t g = 0; // barriers this team has passed: message / count buffers by g & 1, barrier words by g & 3
 
     for (uint32_t turn = 0;; turn++) {
         // ---- the team's next slot: member 0 draws it, the others read it from the team's sequence
-        if (tid == 0) {
-            uint32_t s = TEAM_EMPTY;
-            bool ok = true;
-            if (me == 0) {
-                s = atomicAdd(&a.ctl[0], 1u);
-                __hip_atomic_store(&seq[turn], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                ok = team_wait(a, a.err, [&] { s = __hip_atomic_load(&seq[turn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return s != TEAM_EMPTY; });
+        uint32_t q, src, src_deg, src_owner, src_local;
+        bool src_spare; // the source has no in-edge: it uses the spare id R
+        uint64_t slab;
+        {
+            const TeamArgs a = team_args();
+            const uint32_t nq = (uint32_t)a->nq;
+            if (fresh(tid0) == 0) {
+                uint32_t *seq = a->slot_seq + (uint64_t)team * (nq + 2);
+                uint32_t s = TEAM_EMPTY;
+                bool ok = true;
+                if (me == 0) {
+                    s = atomicAdd(&a->ctl[0], 1u);
+                    __hip_atomic_store(&seq[turn], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    ok = team_wait([&] { s = __hip_atomic_load(&seq[turn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return s != TEAM_EMPTY; });
+                }
+                s_slot = s; s_ok = ok ? 1u : 0u;
             }
-            s_slot = s; s_ok = ok ? 1u : 0u;
+            __syncthreads();
+            if (!s_ok) return;
+            q = s_slot;
+            TSTAMP(7);
+            if (q >= nq) break;
+            src = (uint32_t)a->src[q];
+            src_deg = a->deg[src];
+            if (src_deg == 0) continue; // dangling source: k_init_batch has written the whole answer (algo.h:961-965)
+            slab = (uint64_t)q * (uint32_t)a->n;
+            src_owner = (src >> 6) % T;
+            const uint32_t src_word = a->n2l[src];
+            src_spare = src_word == TEAM_EMPTY;
+            src_local = src_spare ? R : (src_word & TEAM_LMASK); // no in-edge: the spare id
         }
-        __syncthreads();
-        if (!s_ok) return;
-        const uint32_t q = s_slot;
-        TSTAMP(7);
-        if (q >= (uint32_t)a.nq) break;
-        const uint32_t src = (uint32_t)a.src[q];
-        const uint32_t src_deg = a.deg[src];
-        if (src_deg == 0) continue; // dangling source: k_init_batch has written the whole answer (algo.h:961-965)
-        const uint64_t slab = (uint64_t)q * a.n;
-        const uint32_t src_owner = (src >> 6) % T;
-        const uint32_t src_word = a.n2l[src];
-        const uint32_t src_local = src_word == TEAM_EMPTY ? R : (src_word & TEAM_LMASK); // no in-edge: the spare id
         uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
         uint32_t peak = 0, nlev = 0;
         uint32_t logbase = 0;     // my pops of the slot's levels so far = entries of my reserve log
         bool final_round = false;
-        if (tid == 0) s_rsvovf = 0;
+        if (fresh(tid0) == 0) s_rsvovf = 0;
 
 #ifdef FORA_STAMPS_LEVELS
         long long lv_t_ = clock64();
 #endif
         for (uint32_t L = 0;; L++) {
+            const int tid = fresh(tid0), lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6); // this level's copies (see fresh())
             // ================= consume: the messages of the previous level that are addressed to me
             if (L > 0) {
-                const uint32_t *min_ = a.msg + ((uint64_t)team * 2 + ((g - 1) & 1u)) * cap_total;
-                const uint64_t *tin = a.inct + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * tstride;
+                const TeamArgs a = team_args();
+                const uint32_t par = (g - 1) & 1u;
+                const uint32_t *min_ = a->msg + ((uint64_t)team * 2 + par) * cap_total;
+                const uint64_t *tin = a->inct + ((uint64_t)team * 2 + par) * T * tstride;
                 // There is no barrier between the levels: member s ends a level by writing ONE word per destination d -- the
                 // messages in bucket (s -> d) | its pops << 24 | a tag of the level's number << 40 -- and every wave of d polls
                 // the T words addressed to d and consumes the buckets of the sources that are through, while the slower ones
@@ -311,22 +348,26 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 // from a scan of the per-source counts and a ballot -- no table, no search.  CU segments per trip: all message
                 // loads in flight together (two messages per lane), then all increment gathers.
                 const uint32_t tagp = g & 0xFFFFFFu; // (the tag of barrier g - 1)
-                const unsigned long long *cwin = a.cntw + ((uint64_t)team * 2 + ((g - 1) & 1u)) * T * T + (uint64_t)me * T;
+                const unsigned long long *cwin = a->cntw + ((uint64_t)team * 2 + par) * T * T + (uint64_t)me * T;
                 const unsigned long long full = T >= 64 ? ~0ull : (1ull << T) - 1ull;
                 unsigned long long donemask = 0;
                 uint32_t fsum = 0, spins = 0;
-                const uint64_t w_t0 = wall_clock64();
+                uint64_t w_t0 = 0;
                 while (donemask != full) {
                 unsigned long long wv = 0;
                 if ((uint32_t)lane < T) wv = __hip_atomic_load(&cwin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1: past L1, like every load of handed-over data)
                 const unsigned long long ready = __ballot((uint32_t)lane < T && (uint32_t)(wv >> 40) == tagp) & ~donemask;
                 if (!ready) {
                     __builtin_amdgcn_s_sleep(2);
-                    if ((++spins & 255u) == 0) {
-                        bool stop = __hip_atomic_load(&a.ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                        if (!stop && wall_clock64() - w_t0 > a.timeout_ticks) {
-                            __hip_atomic_store(&a.ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (lane == 0) atomicOr(a.err, ERR_TEAM_TIMEOUT);
+                    if ((++spins & 255u) == 0) { // (rare: its operands are read here, not held through the loop)
+                        const TeamArgs ar = team_args();
+                        uint32_t *ctl = ar->ctl;
+                        const uint64_t now = wall_clock64();
+                        if (w_t0 == 0) w_t0 = now;
+                        bool stop = __hip_atomic_load(&ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (!stop && now - w_t0 > ar->timeout_ticks) {
+                            __hip_atomic_store(&ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) atomicOr(ar->err, ERR_TEAM_TIMEOUT);
                             stop = true;
                         }
                         if (stop) { if (lane == 0) s_abort = 1u; break; }
@@ -387,7 +428,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const uint32_t F = s_F;
                 if (F) nlev++;
                 peak = max(peak, F);
-                final_round = F == 0 || (a.tail_max && F <= a.tail_max && (peak > a.tail_max || a.tail_always));
+                const TeamArgs af = team_args();
+                const uint32_t tail_max = af->tail_max;
+                final_round = F == 0 || (tail_max && F <= tail_max && (peak > tail_max || af->tail_always));
             }
             // ================= sweep: who is at or over the threshold (algo.h:1012).  Thread t looks at local ids
             // it * 1024 + t, i.e. wave w at the 64-id groups it * 16 + w; no global load (out-degrees in registers).
@@ -396,20 +439,24 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if (tid == 0) { s_dang = 0; s_ncross = 0; s_nheavy = 0; s_gnext = 0; s_hchunks = 0; s_hnext = 0; s_wdone = 0; s_hubent = 0; }
             if (tid < TEAM_NHEAVY) h_deg[tid] = 0;
             if (L > 0) {
+                const TeamArgs a = team_args();
+                const uint64_t t1 = a->t1;
+                const bool thr_small = (t1 >> 47) == 0;                    // then a 16-bit degree's threshold is two multiplies
+                const uint32_t t1_lo = (uint32_t)t1, t1_hi = (uint32_t)(t1 >> 32);
                 constexpr int SG = 5; // LDS reads in flight together
 #pragma unroll
                 for (int g0 = 0; g0 < TEAM_NIT; g0 += SG) {
-                    if ((uint32_t)g0 < nit) { // wave-uniform
+                    if ((uint32_t)g0 * TEAM_THREADS + (uint32_t)wid * 64u < R) { // (scalar: R is a multiple of 64, a wave's ids are all below it or none is)
                         uint64_t r[SG];
 #pragma unroll
                         for (int k = 0; k < SG; k++) {
                             const uint32_t l = (g0 + k) * TEAM_THREADS + tid;
-                            r[k] = ((uint32_t)(g0 + k) < nit && l < R) ? res[l] : 0ull;
+                            r[k] = ((uint32_t)(g0 + k) * TEAM_THREADS + (uint32_t)wid * 64u < R) ? res[l] : 0ull;
                         }
 #pragma unroll
                         for (int k = 0; k < SG; k++) {
                             const int it = g0 + k;
-                            if ((uint32_t)it < nit) { // wave-uniform
+                            if ((uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R) { // scalar
                                 bool c = false;
                                 if (r[k]) {
                                     uint32_t dg = (dgp[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu;
@@ -417,22 +464,22 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                     if (dg == 0xFFFFu) { // a hub: its exact degree
                                         uint32_t li = it * TEAM_THREADS + tid;
                                         asm volatile("" : "+v"(li)); // (keeps the fifteen addresses of this rare path out of the level loop's registers)
-                                        c = r[k] >= node_thr(a.t1, a.deg[l2n[li]]);
+                                        const TeamArgs ar = team_args();
+                                        c = r[k] >= node_thr(t1, ar->deg[ar->l2n[(uint64_t)me * R + li]]);
                                     }
                                     else if (thr_small) c = r[k] >= (uint64_t)t1_lo * dg + ((uint64_t)(t1_hi * dg) << 32); // t1 < 2^47, dg < 2^16: no overflow (dg 0: any residue crosses)
-                                    else c = r[k] >= node_thr(a.t1, dg);
+                                    else c = r[k] >= node_thr(t1, dg);
                                 }
                                 if (c) crossmask |= 1u << it;
                                 const unsigned long long mk = __ballot(c);
-                                const uint32_t gi = it * TEAM_NW + wid;
-                                if (lane == 0 && gi < ngroups - 1) s_gmask[gi] = mk;
+                                if (lane == 0) s_gmask[it * TEAM_NW + wid] = mk; // (group it * 16 + wid < R / 64: not the spare id's)
                             }
                         }
                     }
                 }
                 if (tid == 0) { // the spare id (the source, if it has no in-edge: only dangling mass ever lands there)
                     const uint64_t rs = res[R];
-                    s_gmask[ngroups - 1] = (me == src_owner && rs && rs >= node_thr(a.t1, src_deg)) ? 1ull : 0ull;
+                    s_gmask[ngroups - 1] = (me == src_owner && rs && rs >= node_thr(t1, src_deg)) ? 1ull : 0ull;
                 }
             } else if (me == src_owner && tid == 0) { // the source is popped whatever its threshold (algo.h:969-978)
                 res[src_local] = FIX_ONE;
@@ -442,18 +489,24 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             if (final_round) {
                 // ================= hand-over: crossing nodes -> (node, residue taken) entries of the slot's frontier list
                 // (k_push_tail pops them, see k_accum), then my residue range -> the slot's slab
+                const TeamArgs a = team_args();
+                const uint32_t n = (uint32_t)a->n;
+                const uint32_t *l2n = a->l2n + (uint64_t)me * R;
+                uint32_t *fl0 = a->fl0 + slab;
+                uint64_t *inc0 = a->inc_tab0 + (uint64_t)q * a->segq_cap;
+                uint64_t *residue = a->residue + slab;
                 uint32_t mine = 0;
                 for (uint32_t it = 0; it < nit; it++) mine += (uint32_t)__popcll(__ballot((crossmask >> it) & 1u));
                 const bool spare = wid == 0 && s_gmask[ngroups - 1] != 0; // (wave-uniform)
                 if (spare) mine++;
                 if (mine) { // wave-uniform
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&a.fl_count0[q * CSTRIDE], mine);
+                    if (lane == 0) base = atomicAdd(&a->fl_count0[q * CSTRIDE], mine);
                     base = __shfl(base, 0);
                     if (spare) {
                         if (lane == 0) {
-                            if (base < (uint32_t)a.n) { a.fl0[slab + base] = src; a.inc_tab0[(uint64_t)q * a.segq_cap + base] = res[R]; }
-                            else atomicOr(a.err, ERR_WL_OVERFLOW);
+                            if (base < n) { fl0[base] = src; inc0[base] = res[R]; }
+                            else atomicOr(a->err, ERR_WL_OVERFLOW);
                             res[R] = 0;
                         }
                         base++;
@@ -463,11 +516,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const unsigned long long mk = __ballot(c);
                         if (c) {
                             const uint32_t l = it * TEAM_THREADS + tid;
-                            const uint32_t pos = base + (uint32_t)__popcll(mk & lt_mask);
-                            if (pos < (uint32_t)a.n) {
-                                a.fl0[slab + pos] = l2n[l];
-                                a.inc_tab0[(uint64_t)q * a.segq_cap + pos] = res[l];
-                            } else atomicOr(a.err, ERR_WL_OVERFLOW);
+                            const uint32_t pos = base + (uint32_t)rank_below(mk);
+                            if (pos < n) {
+                                fl0[pos] = l2n[l];
+                                inc0[pos] = res[l];
+                            } else atomicOr(a->err, ERR_WL_OVERFLOW);
                             res[l] = 0;
                         }
                         base += (uint32_t)__popcll(mk);
@@ -475,16 +528,19 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 }
                 for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
                     const uint32_t v = l2n[l];
-                    if (v != TEAM_EMPTY) a.residue[slab + v] = res[l];
+                    if (v != TEAM_EMPTY) residue[v] = res[l];
                     res[l] = 0;
                 }
                 if (tid == 0) { // (the same thread that may have handed the spare id over)
-                    if (me == src_owner && src_word == TEAM_EMPTY) a.residue[slab + src] = res[R];
+                    if (me == src_owner && src_spare) residue[src] = res[R];
                     res[R] = 0;
                 }
                 __syncthreads();
                 // the reserve log of the slot -> sums per local id in the (now empty) LDS -> the slot's ppr slab (zero there so far)
-                const uint32_t nlog = min(logbase, a.rlog_cap);
+                const uint32_t rlog_cap = a->rlog_cap;
+                const uint16_t *rlog_id = a->rlog_id + ((uint64_t)team * T + me) * rlog_cap;
+                const uint64_t *rlog_val = a->rlog_val + ((uint64_t)team * T + me) * rlog_cap;
+                const uint32_t nlog = min(logbase, rlog_cap);
                 for (uint32_t i0 = 0; i0 < nlog; i0 += 8 * TEAM_THREADS) { // (eight entries per thread in flight)
                     uint64_t val[8];
                     uint32_t id[8];
@@ -500,10 +556,12 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 }
                 __syncthreads();
                 const bool ovf = s_rsvovf != 0;
+                uint64_t *rsvl = a->rsvl + ((uint64_t)team * T + me) * R;
+                uint64_t *ppr = a->ppr + slab;
                 for (uint32_t l = tid; l < R; l += TEAM_THREADS) {
                     uint64_t rs = res[l];
                     if (ovf) { const uint64_t o = rsvl[l]; if (o) { rs += o; rsvl[l] = 0; } }
-                    if (rs) { a.ppr[slab + l2n[l]] = rs; res[l] = 0; }
+                    if (rs) { ppr[l2n[l]] = rs; res[l] = 0; }
                 }
                 TSTAMP(6);
                 break;
@@ -511,10 +569,17 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             // ================= pop + emit, every wave on its own.  The waves draw the level's 64-id groups four at a time
             // from a shared counter (a group whose nodes have long rows keeps one wave busy while the others take the
             // rest), collect the crossing nodes in a wave-private list and pop 64 of them at a time.
-            uint32_t *mout = a.msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
-            uint64_t *tout = a.inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride; // my increment table of this level
             uint64_t my_dang = 0;
             {
+                const TeamArgs a = team_args();
+                uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
+                uint64_t *tout = a->inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride; // my increment table of this level
+                const uint64_t *rowl = a->rowl + (uint64_t)me * R;
+                const uint32_t rlog_cap = a->rlog_cap;
+                uint16_t *rlog_id = a->rlog_id + ((uint64_t)team * T + me) * rlog_cap;
+                uint64_t *rlog_val = a->rlog_val + ((uint64_t)team * T + me) * rlog_cap;
+                const uint64_t afix = a->afix;
+                const uint32_t *colt = a->colt;
                 uint16_t *list = w_list[wid];
                 uint64_t *winc = w_inc[wid];
                 uint8_t *mark = w_mark[wid];
@@ -533,7 +598,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         }
                         const uint32_t gi = gcur++;
                         const unsigned long long mk = s_gmask[gi];
-                        if ((mk >> lane) & 1ull) list[npend + (uint32_t)__popcll(mk & lt_mask)] = (uint16_t)(gi * 64 + lane);
+                        if ((mk >> lane) & 1ull) list[npend + (uint32_t)rank_below(mk)] = (uint16_t)(gi * 64 + lane);
                         npend += (uint32_t)__popcll(mk);
                     }
                     if (npend == 0) break;
@@ -542,23 +607,31 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     uint32_t cnt = 0, ebeg = 0;
                     uint32_t ebase = 0; // my entries of the level's increment table: ebase + lane
                     if (lane == 0) ebase = atomicAdd(&s_ncross, m);
-                    ebase = (uint32_t)__shfl((int)ebase, 0);
+                    ebase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ebase);
                     if ((uint32_t)lane < m) {
                         const uint32_t l = list[lane];
                         const bool spare = l == R; // the source without in-edges: no local tables
                         const uint64_t rw = spare ? 0ull : rowl[l];
                         const uint32_t logi = logbase + ebase + (uint32_t)lane;     // my entry of the reserve log
-                        const bool direct = spare || logi >= a.rlog_cap;           // (rare) straight to the accumulator
-                        const uint64_t rsv_old = !direct ? 0ull : spare ? a.ppr[slab + src] : rsvl[l];
-                        const uint64_t ri = spare ? a.rowinfo[src] : 0ull;
+                        const bool direct = spare || logi >= rlog_cap;             // (rare) straight to the accumulator
+                        uint64_t rsv_old = 0, ri = 0;
+                        if (direct) { // (its operands are read here: they do not ride through the level in registers)
+                            const TeamArgs ar = team_args();
+                            rsv_old = spare ? ar->ppr[slab + src] : (ar->rsvl + ((uint64_t)team * T + me) * R)[l];
+                            if (spare) ri = ar->rowinfo[src];
+                        }
                         const uint64_t rr = res[l];
                         res[l] = 0;                                       // algo.h:984-985
-                        uint32_t deg = spare ? team_deg(a, ri, src) : (uint32_t)(rw >> 19) & 8191u;
-                        if (!spare && deg == 8191u) deg = a.deg[(uint32_t)rw & 0x7FFFFu]; // a hub: its exact degree
+                        uint32_t deg = spare ? src_deg : (uint32_t)(rw >> 19) & 8191u;
+                        if (!spare && deg == 8191u) deg = team_args()->deg[(uint32_t)rw & 0x7FFFFu]; // a hub: its exact degree
                         uint64_t rsv_add, dang;
-                        const uint64_t inc = pop_value(a.afix, rr, deg, rsv_add, dang);
-                        if (logi < a.rlog_cap) { rlog_val[logi] = direct ? 0ull : rsv_add; rlog_id[logi] = direct ? (uint16_t)0 : (uint16_t)l; } // algo.h:986-989, see TeamDev::rlog_id (the spare id's pop leaves an empty entry)
-                        if (direct && rsv_add) { if (spare) a.ppr[slab + src] = rsv_old + rsv_add; else { rsvl[l] = rsv_old + rsv_add; s_rsvovf = 1u; } } // (this member owns the node)
+                        const uint64_t inc = pop_value(afix, rr, deg, rsv_add, dang);
+                        if (logi < rlog_cap) { rlog_val[logi] = direct ? 0ull : rsv_add; rlog_id[logi] = direct ? (uint16_t)0 : (uint16_t)l; } // algo.h:986-989, see TeamDev::rlog_id (the spare id's pop leaves an empty entry)
+                        if (direct && rsv_add) { // (this member owns the node)
+                            const TeamArgs ar = team_args();
+                            if (spare) ar->ppr[slab + src] = rsv_old + rsv_add;
+                            else { (ar->rsvl + ((uint64_t)team * T + me) * R)[l] = rsv_old + rsv_add; s_rsvovf = 1u; }
+                        }
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
                         ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
                         cnt = inc ? deg : 0u;
@@ -616,7 +689,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             const uint32_t e = e0 + k;
                             si[k] = si[k] ? si[k] - 1u : 0u;
                             const uint32_t rb = (uint32_t)__shfl((int)rowbase, (int)si[k]);
-                            w[k] = a.colt[e < total ? rb + e : 0u];
+                            w[k] = colt[e < total ? rb + e : 0u];
                         }
                         __builtin_amdgcn_sched_barrier(0); // all four loads are on their way before the first is waited for
 #pragma unroll
@@ -651,10 +724,13 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         if (nx < tot) { if (atomicCAS(&s_hnext, nx, nx + 1u) == nx) k = nx; }
                         else if (__atomic_load_n(&s_wdone, __ATOMIC_RELAXED) == (uint32_t)TEAM_NW && nx >= __atomic_load_n(&s_hchunks, __ATOMIC_RELAXED)) fin = 1;
                     }
-                    k = (uint32_t)__shfl((int)k, 0);
-                    fin = (uint32_t)__shfl((int)fin, 0);
+                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)fin);
                     if (fin) break;
                     if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
+                    const TeamArgs a = team_args(); // (a heavy chunk is 256 edges: two scalar loads are nothing beside it)
+                    uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
+                    const uint32_t *colt = a->colt;
                     uint32_t eb = 0, dgh = 0, ent = 0, c0 = 0;
                     uint64_t hinc = 0;
                     for (bool found = false; !found;) { // the row of chunk k (it may still be on its way into the list): lane h looks at entries h, h + 64
@@ -677,7 +753,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const uint32_t e = c0 + kk * 64 + lane;
                         dst[kk] = TEAM_EMPTY; word[kk] = 0;
                         if (e < dgh) {
-                            const uint32_t w = a.colt[(uint64_t)eb + e];
+                            const uint32_t w = colt[(uint64_t)eb + e];
                             if (w & 0x80000000u) atomicAdd(&s_hub[w & 0x7FFFFFFFu], (unsigned long long)hinc);
                             else { dst[kk] = w >> TEAM_LBITS; word[kk] = (w & TEAM_LMASK) | ent; }
                         }
@@ -688,41 +764,51 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
             TSTAMP(6);
             __syncthreads(); // (the message stores are waited for below, together with the counts)
             TSTAMP(7);
-            if (tid == 0 && s_dang) { // one more table entry, one more message
-                const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
-                tout[ent] = s_dang;
-                mout[pos] = src_local | (ent << TEAM_LBITS);
-            }
-            for (uint32_t h = tid; h < H; h += TEAM_THREADS) { // the hubs' sums of this level: one message each
-                const unsigned long long hv = s_hub[h];
-                if (hv) {
-                    s_hub[h] = 0;
-                    const uint32_t tg = a.hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
-                    tout[ent] = hv;
-                    mout[atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
+            {
+                const TeamArgs a = team_args();
+                uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
+                uint64_t *tout = a->inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride;
+                if (tid == 0 && s_dang) { // one more table entry, one more message
+                    const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
+                    tout[ent] = s_dang;
+                    mout[pos] = src_local | (ent << TEAM_LBITS);
                 }
+                if ((uint32_t)tid < H) { // (wave-uniform up to the last wave) the hubs' sums of this level: one message each
+                    const uint32_t *hubtgt = a->hubtgt;
+                    for (uint32_t h = tid; h < H; h += TEAM_THREADS) {
+                        const unsigned long long hv = s_hub[h];
+                        if (hv) {
+                            s_hub[h] = 0;
+                            const uint32_t tg = hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
+                            tout[ent] = hv;
+                            mout[atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message and table stores have completed
+                __syncthreads();                                 // (and s_fill is final)
+                // ================= my words of the level (see the consume): the other members take it from here
+                const uint32_t tag = (g + 1u) & 0xFFFFFFu;
+                if (!same_xcd) {
+                    if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    __syncthreads();
+                }
+                if ((uint32_t)tid < T) {
+                    unsigned long long *cw = team_args()->cntw + ((uint64_t)team * 2 + (g & 1u)) * T * T; // [destination][source]
+                    __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)(s_fill[tid] - s_moff[tid]) | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                logbase += s_ncross; // (s_fill / s_ncross are zeroed in the sweep of the next level: behind the barrier that closes its consume)
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its message and table stores have completed
-            __syncthreads();                                 // (and s_fill is final)
-            // ================= my words of the level (see the consume): the other members take it from here
-            const uint32_t tag = (g + 1u) & 0xFFFFFFu;
-            unsigned long long *cw = a.cntw + ((uint64_t)team * 2 + (g & 1u)) * T * T; // [destination][source]
-            if (!same_xcd) {
-                if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                __syncthreads();
-            }
-            if ((uint32_t)tid < T)
-                __hip_atomic_store(&cw[(uint32_t)tid * T + me], (unsigned long long)(s_fill[tid] - s_moff[tid]) | ((unsigned long long)s_ncross << 24) | ((unsigned long long)tag << 40),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            logbase += s_ncross; // (s_fill / s_ncross are zeroed in the sweep of the next level: behind the barrier that closes its consume)
             TSTAMP(5);
 #ifdef FORA_STAMPS_LEVELS
-            if (tid == 0) { const long long n_ = clock64(); atomicAdd(&a.stamps[L < 31 ? L : 31], (unsigned long long)(n_ - lv_t_)); lv_t_ = n_; }
+            if (tid == 0) { const long long n_ = clock64(); atomicAdd(&team_args()->stamps[L < 31 ? L : 31], (unsigned long long)(n_ - lv_t_)); lv_t_ = n_; }
 #endif
             g++;
         }
         // ---- the slot's counters (algo.h:992 rsum bookkeeping)
         acc_res = wave_sum(acc_res); acc_pops = wave_sum(acc_pops); acc_relax = wave_sum(acc_relax);
+        const int tid = fresh(tid0), lane = tid & 63;
         if (tid < 3) s_acc[tid] = 0;
         __syncthreads();
         if (lane == 0 && acc_pops) {
@@ -732,7 +818,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         }
         __syncthreads();
         if (tid == 0) {
-            QState *s = &a.qs[q];
+            QState *s = &team_args()->qs[q];
             if (s_acc[1]) {
                 atomicAdd(&s->reserved, s_acc[0]);
                 atomicAdd(&s->pops, s_acc[1]);

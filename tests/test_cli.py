@@ -102,7 +102,7 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
     total, _, _ = oracle.index_sizes(g, rmax, omega)
     assert f"tuned_index_size={total}" in r.stdout
     for extra in ([], ["--with_idx"]):
-        r = _run([cli, "query", "--algo", "fora", "--query_size", "10", *common, *extra])
+        r = _run([cli, "query", "--algo", "fora", "--query_size", "10", *common, *extra], env={**os.environ, "FORA_CLI_TIMING": "1"})
         assert r.returncode == 0, r.stderr
         assert "1. source node:%d" % queries[0] in r.stdout and "10. source node:%d" % queries[9] in r.stdout
         assert "11. source node" not in r.stdout                      # min(file, --query_size), query.h:1419
@@ -118,6 +118,16 @@ def test_cli_build_query_topk_end_to_end(cli, oracle, small, tmp_path):
         walks = sum(oracle.twin_query(g, int(s), rmax, omega, seed=0x464F5241)[2]["n_walks"] for s in queries[:10])
         assert float(j["result"]["total number of rand-walks"]) == walks
         assert set(j["timer"]) >= {"3", "5", "6"}
+        # config.h:47-57 slots 5 (FWD_LU) / 6 (RONDOM_WALK) / 3 (FORA_QUERY) and the lines of algo.h:368-402 carry the
+        # engine's real kernel times: the push slot covers every push kernel (round 4 left k_push_team out of it)
+        et = dict(kv.split("=") for kv in next(l for l in r.stderr.splitlines() if l.startswith("engine_timing")).split()[1:])
+        t3, t5, t6 = (float(j["timer"][k]) for k in ("3", "5", "6"))
+        assert float(et["push_ms"]) > 0 and t5 >= 0.8 * float(et["push_ms"]) * 1e-3
+        assert t6 >= 0.8 * float(et["walk_ms"]) * 1e-3
+        assert t5 + t6 <= t3 * 1.001
+        pct = {l.split("%")[1].strip(): float(l.split("%")[0]) for l in r.stdout.splitlines() if "% for " in l}
+        assert pct["for forward push cost"] + pct["for random walk cost"] <= 100.0 + 1e-6
+        assert abs(pct["for forward push cost"] - 100.0 * t5 / t3) < 0.5
     # the same index as Boost binary archives (build --boost_idx): same content, read back by query --with_idx
     h_native = _run([cli, "check-index", *common]).stdout.strip().split("\n")[-1]
     r = _run([cli, "build", "--boost_idx", *common])
