@@ -65,7 +65,8 @@ struct Tunables {
     int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
     int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
-    int64_t team_coop = -1;      // k_push_team launch: 1 hipLaunchCooperativeKernel (all workgroups co-resident or the launch fails; cooperative kernels of different contexts do not interleave), 0 plain launch behind an occupancy check, -1: cooperative when the device reports support
+    int64_t team_coop = 0;       // k_push_team launch: 0 (default) plain launch behind an occupancy check (occupancy x CUs >= grid, team_fits); 1: hipLaunchCooperativeKernel.  Measured on ROCm 7.2 / MI355X (round 5): the cooperative
+                                 // launch costs ~9 ms per launch (push of 64 ws-sized queries 14.8 ms against 5.6: the runtime moves the launch to its cooperative queue and back) and a process with two contexts that used it crashed in the runtime's teardown -- opt-in only
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -130,6 +131,7 @@ struct fora_ctx {
     uint16_t *d_team_rlog_id = nullptr; uint64_t *d_team_rlog_val = nullptr; uint32_t team_rlog_cap = 0; // reserve logs (TeamDev::rlog_id)
     uint64_t *d_team_rowl = nullptr, *d_team_rsvl = nullptr; // rows by local id (graph); reserve accumulators by local id (workspace)
     uint16_t *d_team_deg16 = nullptr;
+    uint32_t *d_team_rowq = nullptr; // [n] first quad of every node's row in d_colt
     uint32_t team_T = 0, team_R = 0, team_force = 0; // members per team, local ids per member; the team_size option they were built for
     bool team_checked = false, team_wanted = false;  // ensure_team has looked at this graph with these options
     double dangling_frac = 0;        // share of the nodes without out-edges
@@ -257,7 +259,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt); c->team_H = 0; c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
+    dfree(c->d_colt); dfree(c->d_team_rowq); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt); c->team_H = 0; c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
     c->split_pbins = 0;
@@ -435,7 +437,7 @@ int ensure_team(fora_ctx *c) {
     const uint32_t hubs_opt = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_hubs, 0), 4096);
     if (c->team_checked && want == c->team_wanted && (!want || (c->team_force == force && c->team_hubs_opt == hubs_opt))) return FORA_OK;
     c->team_checked = true; c->team_wanted = want;
-    dfree(c->d_colt); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt);
+    dfree(c->d_colt); dfree(c->d_team_rowq); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt);
     c->team_H = 0; c->team_hubs_opt = hubs_opt;
     c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_force = force;
     if (!want) return FORA_OK;
@@ -468,8 +470,13 @@ int ensure_team(fora_ctx *c) {
         l2n[(size_t)s * R + l] = (uint32_t)v;
         const int64_t dg = c->h_row_ptr[v + 1] - c->h_row_ptr[v];
         deg16[(size_t)s * R + l] = (uint16_t)std::min<int64_t>(dg, 0xFFFF);
-        rowl[(size_t)s * R + l] = (uint64_t)v | ((uint64_t)std::min<int64_t>(dg, 8191) << 19) | ((uint64_t)c->h_row_ptr[v] << 32); // n <= 2^19, nnz < 2^32 in this layout
+        rowl[(size_t)s * R + l] = (uint64_t)v | ((uint64_t)std::min<int64_t>(dg, 8191) << 19); // n <= 2^19; the row's first quad (<< 32) follows below
     }
+    // rows of the team copy are padded to whole quads (four words, 16-byte aligned): a lane reads a quad with one load
+    std::vector<uint32_t> rowq(n + 1, 0);
+    for (size_t v = 0; v < n; v++) rowq[v + 1] = rowq[v] + (uint32_t)((c->h_row_ptr[v + 1] - c->h_row_ptr[v] + 3) / 4); // (< 2^32: nnz < 2^32, want_team)
+    for (size_t v = 0; v < n; v++)
+        if (n2l[v] != TEAM_EMPTY) rowl[(size_t)(n2l[v] >> TEAM_LBITS) * R + (n2l[v] & TEAM_LMASK)] |= (uint64_t)rowq[v] << 32;
     // hubs: the nodes of largest in-degree (ties: lower id); their sums travel as one message per member and level
     // (their LDS sums share the 160 KiB with the residues and ~23 KB of static arrays)
     const uint64_t lds_left = 163840 / TEAM_WGS_PER_CU - 23 * 1024 - ((uint64_t)R + 1) * 8;
@@ -483,13 +490,13 @@ int ensure_team(fora_ctx *c) {
                           [&](uint32_t x, uint32_t y) { return indeg[x] != indeg[y] ? indeg[x] > indeg[y] : x < y; });
         for (uint32_t h = 0; h < Hn; h++) if (indeg[order[h]]) { hub_of[order[h]] = h; hubtgt[h] = n2l[order[h]]; hub_ok[h] = 1; }
     }
-    std::vector<uint32_t> colt(nnz);
+    std::vector<uint32_t> colt((size_t)rowq[n] * 4, TEAM_EMPTY);
     std::vector<uint64_t> pair((size_t)T * T, 0);
     for (size_t v = 0; v < n; v++) {
         const uint32_t s = (uint32_t)((v >> 6) % T);
         for (int64_t e = c->h_row_ptr[v]; e < c->h_row_ptr[v + 1]; e++) {
             const uint32_t t = (uint32_t)col[(size_t)e], w = n2l[t];
-            colt[(size_t)e] = hub_of[t] != TEAM_EMPTY ? (0x80000000u | hub_of[t]) : w;
+            colt[(size_t)rowq[v] * 4 + (size_t)(e - c->h_row_ptr[v])] = hub_of[t] != TEAM_EMPTY ? (0x80000000u | hub_of[t]) : w;
             if (hub_of[t] == TEAM_EMPTY) pair[(size_t)s * T + (w >> TEAM_LBITS)]++;
         }
     }
@@ -504,7 +511,9 @@ int ensure_team(fora_ctx *c) {
         if (at >= (1ull << 32) || pair[i] + 1 >= (1ull << 24)) return FORA_OK; // 32-bit slots; a bucket's count is 24 bits of its barrier word: no team push for such a graph
     }
     off[(size_t)T * T] = (uint32_t)at;
-    HIPCHK(c, hipMalloc(&c->d_colt, nnz * 4));
+    HIPCHK(c, hipMalloc(&c->d_colt, colt.size() * 4 + 16));
+    HIPCHK(c, hipMalloc(&c->d_team_rowq, n * 4));
+    HIPCHK(c, hipMemcpy(c->d_team_rowq, rowq.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_team_off, off.size() * 4));
     HIPCHK(c, hipMalloc(&c->d_team_n2l, n * 4));
     HIPCHK(c, hipMalloc(&c->d_team_l2n, l2n.size() * 4));
@@ -514,7 +523,7 @@ int ensure_team(fora_ctx *c) {
     c->team_H = Hn;
     HIPCHK(c, hipMalloc(&c->d_team_rowl, rowl.size() * 8));
     HIPCHK(c, hipMemcpy(c->d_team_rowl, rowl.data(), rowl.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), nnz * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_colt, colt.data(), colt.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_n2l, n2l.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_team_l2n, l2n.data(), l2n.size() * 4, hipMemcpyHostToDevice));
@@ -603,7 +612,11 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             while (c->team_rlog_cap > 1024 && per_team_bytes(c->team_rlog_cap) > fr / 4) c->team_rlog_cap /= 2;
             const uint64_t per_team = per_team_bytes(c->team_rlog_cap);
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
+#if defined(FORA_PROBE_STORE) || defined(FORA_PROBE_STORE2)
+            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64 + (size_t)(80000000) * 4 + (1 << 20)));
+#else
             HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
+#endif
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
@@ -924,7 +937,7 @@ int team_fits(fora_ctx *c) {
     c->team_fit = (uint64_t)per_cu * (uint64_t)c->prop.multiProcessorCount >= grid ? 1 : 0;
     int coop = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess) { (void)hipGetLastError(); coop = 0; }
-    c->team_coop_ok = c->opt_.team_coop == 1 || (c->opt_.team_coop < 0 && coop != 0);
+    c->team_coop_ok = c->opt_.team_coop == 1 && coop != 0;
     return FORA_OK;
 }
 int run_push_team(fora_ctx *c, const Dev &d) {
@@ -934,7 +947,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     a.residue = d.residue; a.ppr = d.ppr; a.fl0 = d.fl[0]; a.fl_count0 = d.fl_count[0]; a.inc_tab0 = d.inc_tab[0];
     a.segq_cap = d.segq_cap; a.qs = d.qs; a.err = d.err; a.afix = d.afix; a.t1 = d.t1;
     a.T = T; a.R = c->team_R; a.nteams = nteams;
-    a.colt = c->d_colt; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.rlog_id = c->d_team_rlog_id; a.rlog_val = c->d_team_rlog_val; a.rlog_cap = c->opt_.team_log == 0 ? 0u : c->opt_.team_log > 0 ? std::min<uint32_t>((uint32_t)c->opt_.team_log, c->team_rlog_cap) : c->team_rlog_cap; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cntw = c->d_team_cnt;
+    a.colt = c->d_colt; a.rowq = c->d_team_rowq; a.n2l = c->d_team_n2l; a.l2n = c->d_team_l2n; a.deg16 = c->d_team_deg16; a.rowl = c->d_team_rowl; a.rsvl = c->d_team_rsvl; a.rlog_id = c->d_team_rlog_id; a.rlog_val = c->d_team_rlog_val; a.rlog_cap = c->opt_.team_log == 0 ? 0u : c->opt_.team_log > 0 ? std::min<uint32_t>((uint32_t)c->opt_.team_log, c->team_rlog_cap) : c->team_rlog_cap; a.H = c->team_H; a.hubtgt = c->d_team_hubtgt; a.off = c->d_team_off; a.msg = c->d_team_msg; a.inct = c->d_team_inct; a.cntw = c->d_team_cnt;
     a.ctl = c->d_team_ctl;
     a.sync = (unsigned long long *)(c->d_team_ctl + 64);
     a.slot_seq = c->d_team_ctl + 64 + (size_t)nteams * 5 * 16 * 2;
@@ -1253,7 +1266,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
-    w->d_colt = c->d_colt; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->d_team_hubtgt = c->d_team_hubtgt; w->team_H = c->team_H; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
+    w->d_colt = c->d_colt; w->d_team_rowq = c->d_team_rowq; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->d_team_hubtgt = c->d_team_hubtgt; w->team_H = c->team_H; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;

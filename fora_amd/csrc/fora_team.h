@@ -82,11 +82,13 @@ struct TeamDev {
     uint32_t *err;
     uint64_t afix, t1;
     uint32_t T, R, nteams;         // members per team; local ids per member (a multiple of 64; id R: the slot's source when it has no in-edge); teams of the launch
-    const uint32_t *colt;          // [nnz] owner << 15 | local id of every edge target, rows as in col
+    const uint32_t *colt;          // owner << 15 | local id of every edge target, rows as in col but every row padded with TEAM_EMPTY words to whole QUADS (4 words,
+                                   // 16-byte aligned): a lane reads the four edges of a quad with one 16-byte load, and all four belong to one row
+    const uint32_t *rowq;          // [n] first quad of a node's row (the slot's source when it has no local id)
     const uint32_t *n2l;           // [n] owner << 15 | local id of a node, TEAM_EMPTY for a node without in-edges
     const uint32_t *l2n;           // [T][R] node of a local id (TEAM_EMPTY: unused id)
     const uint16_t *deg16;         // [T][R] its out-degree, saturating at 0xFFFF (then Dev::deg has it)
-    const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first edge << 32: one load per pop, by LOCAL id
+    const uint64_t *rowl;          // [T][R] node (19 bits) | out-degree (13 bits, 8191: look it up) << 19 | first quad of its row in colt << 32: one load per pop, by LOCAL id
     uint64_t *rsvl;                // [nteams][T][R] reserve accumulators by local id (all zero between slots) for the pops that do not fit the member's log below
     // Reserve LOG: a pop's reserve (algo.h:986-989) is not added to the node's accumulator when it happens (a load and a
     // store of a random 8-byte word per pop: a fifth of the kernel's L2 requests) -- the member appends (local id, amount) to
@@ -164,8 +166,12 @@ __device__ __forceinline__ bool team_wait(DONE done) {
 }
 
 #ifdef FORA_STAMPS
-#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool ts_on_ = true; (void)ts_on_;
+#ifdef FORA_STAMPS_SMALL // only the levels whose predecessor popped at most FORA_STAMPS_SMALL nodes of the slot: where the fixed cost of a level goes
+#define TSTAMP(k) do { const long long n_ = clock64(); if (ts_on_) ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
+#else
 #define TSTAMP(k) do { const long long n_ = clock64(); ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
+#endif
 #define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (ts_a_[i_]) atomicAdd(&team_args()->stamps[i_], ts_a_[i_]); } while (0)
 #else
 #define TSTAMP_DECL
@@ -186,11 +192,23 @@ constexpr uint32_t TEAM_HEAVY = FORA_TEAM_HEAVY; // rows of more edges are relax
 constexpr int TEAM_NHEAVY = FORA_TEAM_NHEAVY;       // heavy rows of a level a member can share out (the others stay with the wave that popped them)
 constexpr int TEAM_MAXGROUPS = FORA_TEAM_MAXGROUPS; // 64-id groups of a member at most, the spare id's included
 
+#ifndef FORA_TEAM_STAGE
+#define FORA_TEAM_STAGE 0 // 1 (experiment): a chunk's messages leave sorted by destination through a wave-private LDS stage
+#endif
+// A wave's stage: the messages of a chunk sorted by destination member (counting sort over <= 32 keys: an LDS histogram
+// gives every message its rank, one atomic per (chunk, destination) on the workgroup's fill counters gives the run its
+// place in the bucket), written out with consecutive lanes on consecutive words of a run.
+struct TeamStage {
+    uint32_t msg[TEAM_CHUNK];
+    uint8_t dst[TEAM_CHUNK];
+    uint32_t hist[TEAM_MAX], offs[TEAM_MAX], delta[TEAM_MAX];
+};
 // word[k] / dst[k]: this lane's messages of a chunk (dst TEAM_EMPTY: none).  s_fill[d]: the next free slot of my bucket
 // (me -> d) in the level's message buffer -- one returning LDS add per message; all four in flight together, then the stores.
-// (Measured and dropped: the chunk's messages sorted by destination in a wave-private LDS stage and stored as coalesced
-// runs -- 82-84 ms against 75 at the time: the sort costs more instructions than the scattered stores cost requests.)
-__device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout) {
+// (Measured twice and dropped, rounds 4 and 5: the chunk's messages sorted by destination in a wave-private LDS stage and
+// stored as coalesced runs, -DFORA_TEAM_STAGE=1.)
+__device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout, uint32_t T) {
+#if !FORA_TEAM_STAGE
     uint32_t slot[TEAM_EPT];
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++) {
@@ -200,6 +218,42 @@ __device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], cons
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++)
         if (dst[k] != TEAM_EMPTY) mout[slot[k]] = word[k];
+#else
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < TEAM_MAX) st.hist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank[TEAM_EPT];
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++) {
+        rank[k] = 0;
+        if (dst[k] != TEAM_EMPTY) rank[k] = atomicAdd(&st.hist[dst[k]], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t c = lane < T ? st.hist[lane] : 0u;
+    uint32_t total;
+    const uint32_t ex = wave_excl_scan(c, total);
+    if (lane < T) {
+        const uint32_t gp = c ? atomicAdd(&s_fill[lane], c) : 0u;
+        st.offs[lane] = ex;
+        st.delta[lane] = gp - ex; // bucket slot of stage entry i of this destination: delta + i
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < TEAM_EPT; k++) {
+        if (dst[k] != TEAM_EMPTY) {
+            const uint32_t slot = st.offs[dst[k]] + rank[k];
+            st.msg[slot] = word[k];
+            st.dst[slot] = (uint8_t)dst[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < TEAM_EPT; j++) {
+        const uint32_t i = j * 64 + lane;
+        if (i < total) mout[st.delta[st.dst[i]] + i] = st.msg[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
 }
 
 // grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * (R + 1) bytes.
@@ -212,13 +266,14 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint16_t w_list[TEAM_NW][128];                // per wave: local ids of crossing nodes waiting to be popped
     __shared__ unsigned long long s_gmask[TEAM_MAXGROUPS];   // crossing nodes of every 64-id group of the level
     __shared__ uint32_t h_ent[TEAM_NHEAVY], h_ebeg[TEAM_NHEAVY], h_deg[TEAM_NHEAVY], h_cstart[TEAM_NHEAVY]; // heavy rows of the level: table entry, first edge, degree (written last: 0 = not there yet), first chunk number
-    __shared__ uint8_t w_mark[TEAM_NW][TEAM_CHUNK] __attribute__((aligned(4))); // per wave: row marks of a chunk's edges
+    __shared__ uint8_t w_mark[TEAM_NW][64] __attribute__((aligned(4))); // per wave: row marks of a chunk's quads
     __shared__ uint64_t w_inc[TEAM_NW][64];                  // per wave: increments of the nodes of its batch (hub edges add them in LDS)
     __shared__ uint64_t h_inc[TEAM_NHEAVY];
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
+    __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // next free slot of my bucket (me -> d) in the level's message buffer; its first slot
-    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf;
+    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf, s_nfront;
     __shared__ unsigned long long s_dang, s_acc[3];
     (void)kernarg_only;
 
@@ -325,7 +380,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         uint32_t peak = 0, nlev = 0;
         uint32_t logbase = 0;     // my pops of the slot's levels so far = entries of my reserve log
         bool final_round = false;
-        if (fresh(tid0) == 0) s_rsvovf = 0;
+        if (fresh(tid0) == 0) { s_rsvovf = 0; s_nfront = 0; }
 
 #ifdef FORA_STAMPS_LEVELS
         long long lv_t_ = clock64();
@@ -411,6 +466,15 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         va[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         vb[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+#ifdef FORA_PROBE_GATHER // what does ONE MORE scattered 8-byte gather per message cost?  (another line of the same table; adds 0)
+#pragma unroll
+                    for (int k = 0; k < CU; k++) {
+                        const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
+                        const uint64_t xa = __hip_atomic_load((const unsigned long long *)&tb[left[k] ? ((m[k].x >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint64_t xb = __hip_atomic_load((const unsigned long long *)&tb[left[k] > 1 ? ((m[k].y >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        va[k] += xa >> 63; vb[k] += xb >> 63; // (values are below 2^62)
+                    }
+#endif
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         if (left[k] && va[k]) atomicAdd((unsigned long long *)&res[m[k].x & TEAM_LMASK], (unsigned long long)va[k]);
@@ -423,6 +487,10 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     if (lane == 63) s_F = fs; // nodes the team popped in the level before
                 }
                 __syncthreads();
+#ifdef FORA_STAMPS_SMALL
+                ts_on_ = s_F <= (uint32_t)(FORA_STAMPS_SMALL) && s_F > 0;
+                if (ts_on_) ts_a_[4]++; // (levels counted)
+#endif
                 TSTAMP(0);
                 if (s_abort) return;
                 const uint32_t F = s_F;
@@ -444,6 +512,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const bool thr_small = (t1 >> 47) == 0;                    // then a 16-bit degree's threshold is two multiplies
                 const uint32_t t1_lo = (uint32_t)t1, t1_hi = (uint32_t)(t1 >> 32);
                 constexpr int SG = 5; // LDS reads in flight together
+                uint32_t nfw = 0;     // crossing nodes this wave has seen
 #pragma unroll
                 for (int g0 = 0; g0 < TEAM_NIT; g0 += SG) {
                     if ((uint32_t)g0 * TEAM_THREADS + (uint32_t)wid * 64u < R) { // (scalar: R is a multiple of 64, a wave's ids are all below it or none is)
@@ -472,11 +541,13 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                 }
                                 if (c) crossmask |= 1u << it;
                                 const unsigned long long mk = __ballot(c);
+                                nfw += (uint32_t)__popcll(mk);
                                 if (lane == 0) s_gmask[it * TEAM_NW + wid] = mk; // (group it * 16 + wid < R / 64: not the spare id's)
                             }
                         }
                     }
                 }
+                if (lane == 0 && nfw) atomicAdd(&s_nfront, nfw);
                 if (tid == 0) { // the spare id (the source, if it has no in-edge: only dangling mass ever lands there)
                     const uint64_t rs = res[R];
                     s_gmask[ngroups - 1] = (me == src_owner && rs && rs >= node_thr(t1, src_deg)) ? 1ull : 0ull;
@@ -585,9 +656,14 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 uint8_t *mark = w_mark[wid];
                 uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
+                // A wave pops up to 64 nodes at a time -- but when my share of the level's frontier is small, 64 at a time would
+                // leave most waves without work while a few walk through several chunks of edges one after the other (in the levels
+                // of at most 8192 nodes per slot, a fifth of the kernel's time, wave 0 spent a third of its cycles waiting for
+                // those).  A batch is my frontier / 16, at least 4: every wave gets its share, a short one.
+                const uint32_t bsz = min(64u, max(4u, (s_nfront + TEAM_NW - 1) / TEAM_NW));
                 if (L == 0) { drained = true; if (me == src_owner && wid == 0) { if (lane == 0) list[0] = (uint16_t)src_local; npend = 1; } }
                 for (;;) {
-                    while (npend < 64) { // look at groups until a batch is full (the list holds 128)
+                    while (npend < bsz) { // look at groups until a batch is full (the list holds 128)
                         if (gcur == gend) {
                             if (drained) break;
                             uint32_t g4 = 0;
@@ -614,11 +690,12 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const uint64_t rw = spare ? 0ull : rowl[l];
                         const uint32_t logi = logbase + ebase + (uint32_t)lane;     // my entry of the reserve log
                         const bool direct = spare || logi >= rlog_cap;             // (rare) straight to the accumulator
-                        uint64_t rsv_old = 0, ri = 0;
+                        uint64_t rsv_old = 0;
+                        uint32_t srcq = 0;
                         if (direct) { // (its operands are read here: they do not ride through the level in registers)
                             const TeamArgs ar = team_args();
                             rsv_old = spare ? ar->ppr[slab + src] : (ar->rsvl + ((uint64_t)team * T + me) * R)[l];
-                            if (spare) ri = ar->rowinfo[src];
+                            if (spare) srcq = ar->rowq[src];
                         }
                         const uint64_t rr = res[l];
                         res[l] = 0;                                       // algo.h:984-985
@@ -633,7 +710,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             else { (ar->rsvl + ((uint64_t)team * T + me) * R)[l] = rsv_old + rsv_add; s_rsvovf = 1u; }
                         }
                         acc_res += rsv_add; my_dang += dang; acc_pops++; acc_relax += deg;
-                        ebeg = spare ? (uint32_t)(ri >> 24) : (uint32_t)(rw >> 32);
+                        ebeg = spare ? srcq : (uint32_t)(rw >> 32); // (first quad of the row)
                         cnt = inc ? deg : 0u;
                         if (cnt) tout[ebase + lane] = inc;
                         winc[lane] = inc;
@@ -654,58 +731,47 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     }
                     npend -= m;
                     uint32_t total;
-                    const uint32_t pre = wave_excl_scan(cnt, total);
+                    const uint32_t qn = (cnt + 3u) >> 2;           // quads of this lane's row
+                    const uint32_t pre = wave_excl_scan(qn, total);
                     TSTAMP(2);
-                    // ---- their out-edges: a lane takes TEAM_EPT consecutive edges of the concatenated rows.  Which row an edge
-                    // belongs to comes from MARKS: every row with edges writes its number at the chunk position of its first edge,
-                    // a lane reads the marks of its edges in one word, and a wave scan ("the last mark so far") fills the gaps --
-                    // about a third of the instructions of the binary search + stepping it replaces (the chunk loop is bound by
-                    // its instruction count: 1.2 per edge at 1.16 CU-cycles per edge).
-                    static_assert(TEAM_EPT == 4, "a lane's marks are one 32-bit word");
-                    const uint32_t rowbase = ebeg - pre; // colt index of edge e of this lane's row: rowbase + e (mod 2^32)
-                    uint32_t carry = 0;                  // row (+ 1) of the last edge of the chunks before
-                    for (uint32_t cb = 0; cb < total; cb += TEAM_CHUNK) {
-                        ((uint32_t *)mark)[lane] = 0;
+                    // ---- their out-edges: a lane takes ONE QUAD (four consecutive edges of one row: one 16-byte load) of the
+                    // concatenated rows.  Which row a quad belongs to comes from MARKS: every row with edges writes its number at the
+                    // chunk position of its first quad, a lane reads the mark of its quad, and a wave scan ("the last mark so far": marks
+                    // grow with the lane, so a prefix maximum) fills the gaps.  (Round 4 read four single edges per lane: four row
+                    // look-ups, four exchanges and four loads per lane and chunk; a vector memory instruction costs the CU's address
+                    // unit its 16+ cycles whatever it carries -- profiles/r05_team_probes.txt.)
+                    static_assert(TEAM_EPT == 4, "a quad is four edges");
+                    const uint32_t rowbase = ebeg - pre; // quad q of the concatenation, in this lane's row: colt quad rowbase + q (mod 2^32)
+                    uint32_t carry = 0;                  // row (+ 1) of the last quad of the chunks before
+                    const uint4 *colt4 = (const uint4 *)colt;
+                    for (uint32_t cb = 0; cb < total; cb += 64) {
+                        if (lane < 16) ((uint32_t *)mark)[lane] = 0;
                         __builtin_amdgcn_wave_barrier();
-                        if (cnt && pre - cb < (uint32_t)TEAM_CHUNK) mark[pre - cb] = (uint8_t)(lane + 1); // (pre >= cb: rows before were marked in their chunk)
+                        if (qn && pre - cb < 64u) mark[pre - cb] = (uint8_t)(lane + 1); // (pre >= cb: rows before were marked in their chunk)
                         __builtin_amdgcn_wave_barrier();
-                        const uint32_t mk4 = ((const uint32_t *)mark)[lane];
-                        const uint32_t m0 = mk4 & 255u, m1 = (mk4 >> 8) & 255u, m2 = (mk4 >> 16) & 255u, m3 = mk4 >> 24;
-                        // (marks grow with the lane: "the last mark so far" is a prefix maximum)
-                        const uint32_t x = wave_incl_scan_max(m3 ? m3 : m2 ? m2 : m1 ? m1 : m0);
-                        const uint32_t below = dpp0<0x138>(x);                 // lane - 1's (lane 0: none)
-                        const uint32_t inh = below ? below : carry;            // the last mark before this lane's edges
+                        const uint32_t mk = mark[lane];
+                        const uint32_t x = wave_incl_scan_max(mk);
                         const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                        const uint32_t row1 = x ? x : carry; // the last mark at or before this lane's quad
                         if (lastx) carry = lastx;
-                        uint32_t si[TEAM_EPT];
-                        si[0] = (m0 ? m0 : inh);
-                        si[1] = (m1 ? m1 : si[0]);
-                        si[2] = (m2 ? m2 : si[1]);
-                        si[3] = (m3 ? m3 : si[2]);
-                        const uint32_t e0 = cb + lane * TEAM_EPT;
-                        uint32_t w[TEAM_EPT];
-#pragma unroll
-                        for (int k = 0; k < TEAM_EPT; k++) { // (every lane takes part in the exchanges; loads without a branch around them)
-                            const uint32_t e = e0 + k;
-                            si[k] = si[k] ? si[k] - 1u : 0u;
-                            const uint32_t rb = (uint32_t)__shfl((int)rowbase, (int)si[k]);
-                            w[k] = colt[e < total ? rb + e : 0u];
-                        }
-                        __builtin_amdgcn_sched_barrier(0); // all four loads are on their way before the first is waited for
-#pragma unroll
-                        for (int k = 0; k < TEAM_EPT; k++)
-                            if (e0 + k >= total) w[k] = TEAM_EMPTY;
+                        const uint32_t si = row1 ? row1 - 1u : 0u;
+                        const uint32_t q = cb + lane;
+                        const uint32_t rb = (uint32_t)__shfl((int)rowbase, (int)si);
+                        uint4 w4 = colt4[q < total ? rb + q : 0u]; // (every lane takes part in the exchange; the load without a branch around it)
+                        if (q >= total) w4 = make_uint4(TEAM_EMPTY, TEAM_EMPTY, TEAM_EMPTY, TEAM_EMPTY);
+                        const uint32_t w[TEAM_EPT] = {w4.x, w4.y, w4.z, w4.w};
+                        const uint32_t entw = (ebase + si) << TEAM_LBITS;
                         uint32_t word[TEAM_EPT], dst[TEAM_EPT];
 #pragma unroll
                         for (int k = 0; k < TEAM_EPT; k++) {
                             dst[k] = w[k] == TEAM_EMPTY ? TEAM_EMPTY : w[k] >> TEAM_LBITS;
-                            word[k] = (w[k] & TEAM_LMASK) | ((ebase + si[k]) << TEAM_LBITS);
+                            word[k] = (w[k] & TEAM_LMASK) | entw;
                             if (w[k] != TEAM_EMPTY && (w[k] & 0x80000000u)) { // a hub: summed here
-                                atomicAdd(&s_hub[w[k] & 0x7FFFFFFFu], (unsigned long long)winc[si[k]]);
+                                atomicAdd(&s_hub[w[k] & 0x7FFFFFFFu], (unsigned long long)winc[si]);
                                 dst[k] = TEAM_EMPTY;
                             }
                         }
-                        team_emit(word, dst, s_fill, mout);
+                        team_emit(w_stage[FORA_TEAM_STAGE ? wid : 0], word, dst, s_fill, mout, T);
                     }
                     TSTAMP(3);
                 }
@@ -748,17 +814,21 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         }
                     }
                     uint32_t word[TEAM_EPT], dst[TEAM_EPT];
+                    {
+                        const uint32_t q = (c0 >> 2) + lane; // my quad of the row (consecutive lanes on consecutive quads: 1 KB per load)
+                        uint4 w4 = make_uint4(TEAM_EMPTY, TEAM_EMPTY, TEAM_EMPTY, TEAM_EMPTY);
+                        if (q < ((dgh + 3u) >> 2)) w4 = ((const uint4 *)colt)[(uint64_t)eb + q];
+                        const uint32_t w[TEAM_EPT] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int kk = 0; kk < TEAM_EPT; kk++) {
-                        const uint32_t e = c0 + kk * 64 + lane;
-                        dst[kk] = TEAM_EMPTY; word[kk] = 0;
-                        if (e < dgh) {
-                            const uint32_t w = colt[(uint64_t)eb + e];
-                            if (w & 0x80000000u) atomicAdd(&s_hub[w & 0x7FFFFFFFu], (unsigned long long)hinc);
-                            else { dst[kk] = w >> TEAM_LBITS; word[kk] = (w & TEAM_LMASK) | ent; }
+                        for (int kk = 0; kk < TEAM_EPT; kk++) {
+                            dst[kk] = TEAM_EMPTY; word[kk] = 0;
+                            if (w[kk] != TEAM_EMPTY) {
+                                if (w[kk] & 0x80000000u) atomicAdd(&s_hub[w[kk] & 0x7FFFFFFFu], (unsigned long long)hinc);
+                                else { dst[kk] = w[kk] >> TEAM_LBITS; word[kk] = (w[kk] & TEAM_LMASK) | ent; }
+                            }
                         }
                     }
-                    team_emit(word, dst, s_fill, mout);
+                    team_emit(w_stage[FORA_TEAM_STAGE ? wid : 0], word, dst, s_fill, mout, T);
                 }
             }
             TSTAMP(6);
@@ -768,6 +838,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const TeamArgs a = team_args();
                 uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
                 uint64_t *tout = a->inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride;
+                if (tid == 0) s_nfront = 0; // (read in the pop phase only, added to in the next sweep: behind two barriers)
                 if (tid == 0 && s_dang) { // one more table entry, one more message
                     const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
                     tout[ent] = s_dang;

@@ -145,7 +145,7 @@ int fora_hip_get_batch(fora_ctx *ctx);
 int fora_hip_set_option(fora_ctx *ctx, const char *name, int64_t value);
 /* Reads a knob back, or one of the engine's read-only state words: "team_members" (members per team of k_push_team; 0:
  * this graph / workspace pushes with the bucketed kernels), "team_cooperative" (1: k_push_team is launched with
- * hipLaunchCooperativeKernel), "team_fallbacks" (calls that were run again through the bucketed push because a team of
+ * hipLaunchCooperativeKernel -- option team_coop, off by default), "team_fallbacks" (calls that were run again through the bucketed push because a team of
  * k_push_team timed out waiting for a member -- its workgroups were not co-resident, e.g. another context's kernels held
  * CUs; the caller sees FORA_OK and the same result bits), "team_suspended" (calls left that do not try the team push
  * after such a time-out). */
