@@ -136,6 +136,7 @@ __device__ __forceinline__ uint32_t rank_below(unsigned long long mk) {
 // A per-thread value the optimiser must treat as new: predicates derived from it (tid < 32, lane == 0 && ...) are not
 // hoisted out of the level loop, where each lived in two scalar registers for the whole launch (130 of them spilled).
 __device__ __forceinline__ int fresh(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ uint32_t fresh_s(uint32_t x) { asm volatile("" : "+s"(x)); return x; } // (the same for a wave-uniform value)
 
 // one poll loop for everything a member waits for: returns false when the launch is being abandoned
 template <class DONE>
@@ -166,13 +167,13 @@ __device__ __forceinline__ bool team_wait(DONE done) {
 }
 
 #ifdef FORA_STAMPS
-#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool ts_on_ = true; (void)ts_on_;
+#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; bool ts_on_ = true; (void)ts_on_;
 #ifdef FORA_STAMPS_SMALL // only the levels whose predecessor popped at most FORA_STAMPS_SMALL nodes of the slot: where the fixed cost of a level goes
 #define TSTAMP(k) do { const long long n_ = clock64(); if (ts_on_) ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
 #else
 #define TSTAMP(k) do { const long long n_ = clock64(); ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
 #endif
-#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (ts_a_[i_]) atomicAdd(&team_args()->stamps[i_], ts_a_[i_]); } while (0)
+#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 10; i_++) if (ts_a_[i_]) atomicAdd(&team_args()->stamps[i_], ts_a_[i_]); } while (0)
 #else
 #define TSTAMP_DECL
 #define TSTAMP(k) do {} while (0)
@@ -192,23 +193,13 @@ constexpr uint32_t TEAM_HEAVY = FORA_TEAM_HEAVY; // rows of more edges are relax
 constexpr int TEAM_NHEAVY = FORA_TEAM_NHEAVY;       // heavy rows of a level a member can share out (the others stay with the wave that popped them)
 constexpr int TEAM_MAXGROUPS = FORA_TEAM_MAXGROUPS; // 64-id groups of a member at most, the spare id's included
 
-#ifndef FORA_TEAM_STAGE
-#define FORA_TEAM_STAGE 0 // 1 (experiment): a chunk's messages leave sorted by destination through a wave-private LDS stage
-#endif
-// A wave's stage: the messages of a chunk sorted by destination member (counting sort over <= 32 keys: an LDS histogram
-// gives every message its rank, one atomic per (chunk, destination) on the workgroup's fill counters gives the run its
-// place in the bucket), written out with consecutive lanes on consecutive words of a run.
-struct TeamStage {
-    uint32_t msg[TEAM_CHUNK];
-    uint8_t dst[TEAM_CHUNK];
-    uint32_t hist[TEAM_MAX], offs[TEAM_MAX], delta[TEAM_MAX];
-};
 // word[k] / dst[k]: this lane's messages of a chunk (dst TEAM_EMPTY: none).  s_fill[d]: the next free slot of my bucket
 // (me -> d) in the level's message buffer -- one returning LDS add per message; all four in flight together, then the stores.
-// (Measured twice and dropped, rounds 4 and 5: the chunk's messages sorted by destination in a wave-private LDS stage and
-// stored as coalesced runs, -DFORA_TEAM_STAGE=1.)
-__device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout, uint32_t T) {
-#if !FORA_TEAM_STAGE
+// (Measured twice and dropped, rounds 4 and 5: the chunk's messages sorted by destination in a wave-private LDS stage --
+// counting sort over the <= 32 destinations, one fill-counter atomic per (chunk, destination) -- and stored with consecutive
+// lanes on consecutive words of a run: 82-84 ms against 75 in round 4, 51.9 against 50.9 in round 5 (both without hub sums,
+// whose LDS the stage needs): the stage's LDS round trips cost what the 4 x fewer write requests save.)
+__device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout) {
     uint32_t slot[TEAM_EPT];
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++) {
@@ -218,41 +209,18 @@ __device__ __forceinline__ void team_emit(TeamStage &st, const uint32_t (&word)[
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++)
         if (dst[k] != TEAM_EMPTY) mout[slot[k]] = word[k];
-#else
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane < TEAM_MAX) st.hist[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t rank[TEAM_EPT];
+#ifdef FORA_PROBE_STORE2 // (probe) one more store per message whose lanes write consecutive words (1) / four runs of 16 words (2)
+    {
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]) & ~63u, lane_ = threadIdx.x & 63u;
 #pragma unroll
-    for (int k = 0; k < TEAM_EPT; k++) {
-        rank[k] = 0;
-        if (dst[k] != TEAM_EMPTY) rank[k] = atomicAdd(&st.hist[dst[k]], 1u);
+        for (int k = 0; k < TEAM_EPT; k++)
+            mout[(size_t)80000000 + base + k * 4096 + (FORA_PROBE_STORE2 == 1 ? lane_ : (lane_ >> 4) * 1024 + (lane_ & 15u) + 5)] = word[k];
     }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t c = lane < T ? st.hist[lane] : 0u;
-    uint32_t total;
-    const uint32_t ex = wave_excl_scan(c, total);
-    if (lane < T) {
-        const uint32_t gp = c ? atomicAdd(&s_fill[lane], c) : 0u;
-        st.offs[lane] = ex;
-        st.delta[lane] = gp - ex; // bucket slot of stage entry i of this destination: delta + i
-    }
-    __builtin_amdgcn_wave_barrier();
+#endif
+#ifdef FORA_PROBE_STORE // (probe) what does ONE MORE scattered 4-byte store per message cost?  (a second copy, FORA_PROBE_STORE words further on)
 #pragma unroll
-    for (int k = 0; k < TEAM_EPT; k++) {
-        if (dst[k] != TEAM_EMPTY) {
-            const uint32_t slot = st.offs[dst[k]] + rank[k];
-            st.msg[slot] = word[k];
-            st.dst[slot] = (uint8_t)dst[k];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < TEAM_EPT; j++) {
-        const uint32_t i = j * 64 + lane;
-        if (i < total) mout[st.delta[st.dst[i]] + i] = st.msg[i];
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < TEAM_EPT; k++)
+        if (dst[k] != TEAM_EMPTY) mout[(size_t)(FORA_PROBE_STORE) + slot[k]] = word[k];
 #endif
 }
 
@@ -271,7 +239,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint64_t h_inc[TEAM_NHEAVY];
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
-    __shared__ TeamStage w_stage[FORA_TEAM_STAGE ? TEAM_NW : 1];
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // next free slot of my bucket (me -> d) in the level's message buffer; its first slot
     __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf, s_nfront;
     __shared__ unsigned long long s_dang, s_acc[3];
@@ -354,7 +321,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 uint32_t *seq = a->slot_seq + (uint64_t)team * (nq + 2);
                 uint32_t s = TEAM_EMPTY;
                 bool ok = true;
-                if (me == 0) {
+                if (fresh_s(me) == 0) {
                     s = atomicAdd(&a->ctl[0], 1u);
                     __hip_atomic_store(&seq[turn], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
@@ -413,7 +380,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 if ((uint32_t)lane < T) wv = __hip_atomic_load(&cwin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1: past L1, like every load of handed-over data)
                 const unsigned long long ready = __ballot((uint32_t)lane < T && (uint32_t)(wv >> 40) == tagp) & ~donemask;
                 if (!ready) {
+#ifdef FORA_STAMPS
+                    { const long long w0_ = clock64(); __builtin_amdgcn_s_sleep(2); ts_a_[8] += (unsigned long long)(clock64() - w0_) + 40; } // (pure waiting inside the consume; + the poll itself)
+#else
                     __builtin_amdgcn_s_sleep(2);
+#endif
                     if ((++spins & 255u) == 0) { // (rare: its operands are read here, not held through the loop)
                         const TeamArgs ar = team_args();
                         uint32_t *ctl = ar->ctl;
@@ -429,6 +400,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     }
                     continue;
                 }
+                // (Measured in round 5 and dropped: ONE L1 invalidate per look -- buffer_inv sc1 -- and plain loads through the L1 for
+                // the messages and the increment gathers instead of loads past it: 46.9 -> 121.9 ms; the invalidate stalls the CU's
+                // whole vector memory path every time.)
                 if (!same_xcd) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 donemask |= ready;
                 const bool mine = (ready >> lane) & 1ull;
@@ -454,8 +428,8 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         left[k] = (have && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
                         srcm[k] = sidx;
                         {
-                            const unsigned long long mm = __hip_atomic_load((const unsigned long long *)(min_ + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)coffv, (int)sidx) + (left[k] ? idx : 0u)),
-                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (buckets hold a multiple of 16 words)
+                            const unsigned long long *mp = (const unsigned long long *)(min_ + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)coffv, (int)sidx) + (left[k] ? idx : 0u)); // (buckets hold a multiple of 16 words)
+                            const unsigned long long mm = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             m[k].x = (uint32_t)mm; m[k].y = (uint32_t)(mm >> 32);
                         }
                     }
@@ -463,8 +437,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
-                        va[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vb[k] = __hip_atomic_load((const unsigned long long *)&tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long *pa = (const unsigned long long *)&tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u], *pb = (const unsigned long long *)&tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u];
+                        va[k] = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vb[k] = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #ifdef FORA_PROBE_GATHER // what does ONE MORE scattered 8-byte gather per message cost?  (another line of the same table; adds 0)
 #pragma unroll
@@ -771,7 +746,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                 dst[k] = TEAM_EMPTY;
                             }
                         }
-                        team_emit(w_stage[FORA_TEAM_STAGE ? wid : 0], word, dst, s_fill, mout, T);
+                        team_emit(word, dst, s_fill, mout);
                     }
                     TSTAMP(3);
                 }
@@ -793,7 +768,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                     fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)fin);
                     if (fin) break;
+#ifdef FORA_STAMPS
+                    if (k == TEAM_EMPTY) { const long long w0_ = clock64(); __builtin_amdgcn_s_sleep(1); ts_a_[9] += (unsigned long long)(clock64() - w0_) + 30; continue; }
+#else
                     if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
+#endif
                     const TeamArgs a = team_args(); // (a heavy chunk is 256 edges: two scalar loads are nothing beside it)
                     uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
                     const uint32_t *colt = a->colt;
@@ -828,7 +807,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             }
                         }
                     }
-                    team_emit(w_stage[FORA_TEAM_STAGE ? wid : 0], word, dst, s_fill, mout, T);
+                    team_emit(word, dst, s_fill, mout);
                 }
             }
             TSTAMP(6);

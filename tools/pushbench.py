@@ -52,7 +52,7 @@ def child(args):
            "rsum_fix_xor": int(np.bitwise_xor.reduce(np.asarray([int(s["rsum_fix"]) for s in st], dtype=np.uint64)))}
     stp = eng.stamps()
     if stp.any():
-        out["stamps_bin_Mcyc"] = [round(int(x) / 1e6 / R, 1) for x in stp[:8]]
+        out["stamps_bin_Mcyc"] = [round(int(x) / 1e6 / R, 1) for x in stp[:10]]
         out["stamps_acc_Mcyc"] = [round(int(x) / 1e6 / R, 1) for x in stp[16:22]]
         out["stamps_raw4"] = int(stp[4]) // R
     print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}), flush=True)
