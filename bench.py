@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--balanced", action="store_true", help="--balanced of the reference CLI (query.h:848-884), MI355X cost model")
     ap.add_argument("--balanced-start", type=float, default=1.0, help="first rmax of --balanced as a multiple of rmax (reference: 8)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--fifo-sample", type=int, default=0,
+                    help="graphs whose FIFO push is too slow for the CPU legs: run this many sources through the FIFO oracle anyway (push only) "
+                         "so that the roofline fraction on in-run counts is printed beside the one on the builder's ratio file")
     ap.add_argument("--cpu-threads", type=int, default=-1,
                     help="threads of the all-cores CPU leg (-1: every host core, 0: skip it)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --balanced timing")
@@ -124,14 +127,72 @@ def cpu_baseline(g, sources, rmax, omega, args, index):
     }, ppops, prelax, pn  # FIFO pops / relaxations summed over the first pn sources
 
 
-def cpu_all_cores(g, sources, rmax, omega, args, index, threads):
+def host_cpus():
+    """What this process may really use of the host: the CPUs of its affinity mask (not os.cpu_count(), which counts the
+    machine's), the physical cores behind them (hardware threads that share a core counted once) and the cgroup's CPU
+    quota if there is one."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        cores.setdefault(sib, []).append(c)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # one CPU per physical core first, then the sibling threads: T threads bind to the first T entries
+    order = [v[0] for v in cores.values()] + [c for v in cores.values() for c in v[1:]]
+    usable = len(allowed) if quota is None else max(1, min(len(allowed), int(quota)))
+    return {"hardware_threads_allowed": len(allowed), "physical_cores_allowed": len(cores), "cgroup_cpu_quota": quota,
+            "threads_usable": usable, "machine_hardware_threads": os.cpu_count(), "model": model, "bind_order": order}
+
+
+def cpu_all_cores(g, sources, rmax, omega, args, index, threads, host):
     """the same oracle on T host threads, sources t, t + T, ... per thread -- pthreads inside the
-    oracle (orc_query_many), every thread with its own buffers for the whole run.  (Round 3 drove per-call-allocating
-    ctypes calls from a Python thread pool: 10x one thread on 256 threads.)"""
+    oracle (orc_query_many_pinned), every thread bound to one CPU of the process's affinity mask (physical cores first)
+    and with its own buffers, allocated after binding, for the whole run.  Also a short scaling row (T = 1, 8, 64, ...)
+    so that the all-core figure can be read against the single-thread one."""
     import oracle_lib as O
-    done, dt, _ = O.query_many(g, sources, rmax, omega, threads, args.cpu_seconds, opt=args.opt, seed=0x464F5241, index=index)
-    return {"value": done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{done} of the bench sources over {threads} pthreads (sources tid mod T, private buffers), {dt:.1f} s"}
+    order = host["bind_order"]
+    rows = []
+    ladder = sorted({t for t in (1, 8, 64, host["physical_cores_allowed"], threads) if 1 <= t <= threads})
+    budget = max(2.0, args.cpu_seconds / 3.0)
+    for t in ladder:
+        done, dt, _ = O.query_many(g, sources, rmax, omega, t, budget if t != threads else args.cpu_seconds, opt=args.opt,
+                                   seed=0x464F5241, index=index, cpus=order[:max(1, min(t, len(order)))])
+        rows.append({"threads": t, "queries": done, "seconds": dt, "value": done / dt})
+    top = rows[-1]
+    one = rows[0]["value"] if rows[0]["threads"] == 1 else None
+    return {"value": top["value"], "unit": "queries/s", "cores": host["physical_cores_allowed"], "threads": threads, "kind": "port",
+            "sample": f"{top['queries']} of the bench sources over {threads} pinned pthreads (sources tid mod T, private buffers), {top['seconds']:.1f} s",
+            "scaling": rows, "speedup_over_one_thread": (top["value"] / one) if one else None,
+            "host": {k: v for k, v in host.items() if k != "bind_order"},
+            "note": "every thread runs whole queries (a webstanford-sized query is 6.5 M scattered 8-byte read-modify-writes and 16 M "
+                    "dependent walk steps over ~11 MB of private arrays); cores = physical cores the process may use, threads = pthreads started"}
 
 
 def accuracy(eng, g, sources, n, m, args, np):
@@ -386,9 +447,10 @@ def run_workload(args, ctx, light=False):
             cpu, fp, fe, fn_ = cpu_baseline(g, mine, rmax, omega, args, index)
             p_fifo, e_fifo, counts_from = scale_fifo_counts(fp, fe, fn_, last, tm, q_timed)
             out["cpu_baseline"] = cpu
-            threads = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
+            host = host_cpus()
+            threads = host["threads_usable"] if args.cpu_threads < 0 else min(args.cpu_threads, host["hardware_threads_allowed"])
             if threads > 1 and cpu["value"] * args.cpu_seconds >= 10:  # every thread runs at least one whole query: only when one fits the budget ten times over
-                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads)
+                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads, host)
         elif per_query_guess <= 5.0:  # N > 1 or an extra configuration: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
             g = O.Graph(n, m, row_ptr, col)
             t1 = time.perf_counter()
@@ -408,6 +470,17 @@ def run_workload(args, ctx, light=False):
                 p_fifo = fr[0] * tm["pops"] / max(1, q_timed)
                 e_fifo = fr[1] * tm["relax"] / max(1, q_timed)
                 counts_from = f"GPU schedule counts x FIFO/GPU ratios (pops {fr[0]:.3f}, relaxations {fr[1]:.3f}) of a builder run: {fr[2]}"
+                out["_fifo_ratio_file"] = fr[:2]
+            if args.fifo_sample > 0:  # ... and ONE source through the FIFO oracle here (about a minute of one core at Twitter-2010 size): the in-run fraction
+                import oracle_lib as O
+                g = O.Graph(n, m, row_ptr, col)
+                pp = pr = pn = 0
+                t1 = time.perf_counter()
+                for s in mine[:args.fifo_sample]:
+                    ps = O.push_fifo(g, int(s), rmax)
+                    pp += ps["pops"]; pr += ps["relax"]; pn += 1
+                sp, se, sdesc = scale_fifo_counts(pp, pr, pn, last, tm, q_timed)
+                out["_fifo_in_run"] = (sp, se, sdesc + f" ({time.perf_counter() - t1:.0f} s of one core)")
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = (f"one oracle query on this graph needs about {per_query_guess:.0f} s of one core, more than "
                                         f"--cpu-seconds {args.cpu_seconds:g}; raise it to time the CPU port here")
@@ -441,7 +514,10 @@ def run_workload(args, ctx, light=False):
         e_unit = e_fifo if e_fifo is not None else tm["relax"] / max(1, q_timed)
         p_unit = p_fifo if p_fifo is not None else tm["pops"] / max(1, q_timed)
         team = tm.get("push_team_launches", 0) > 0  # k_push_team: ONE launch per batch runs every level (fora_team.h)
-        launches = tm["push_expand_launches"] + tm["push_tail_launches"] + tm.get("push_team_launches", 0)  # bin-kernel launches (levels x passes) / team launches + the tail launch per batch
+        # the unit of `achieved` / `traffic`: one launch of the dominant kernel WITH what belongs to it -- bucketed push: a level
+        # launch of the bin kernel + its accumulate (the one k_push_tail of a batch counted as a launch of its own); team
+        # push: the ONE k_push_team launch of a batch + the k_push_tail launch that finishes its slots (= the push of a batch)
+        launches = tm["push_team_launches"] if team else tm["push_expand_launches"] + tm["push_tail_launches"]
         bucketed = tm["push_accum_launches"] > 0 or team
         # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
         # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
@@ -467,7 +543,7 @@ def run_workload(args, ctx, light=False):
                 # all push kernels of the profiled batch, per level launch (the unit `achieved` uses): the bin
                 # kernel's launches plus the one k_push_tail that finishes the small levels
                 n_launch = sum(pmc[k].get("FETCH_SIZE_dispatches", 0) for k in keys
-                               if k.startswith(prefixes[0]) or k.startswith("fora::k_push_tail"))
+                               if k.startswith(prefixes[0]) or (not team and k.startswith("fora::k_push_tail")))
                 traffic = sum(pmc[k].get("FETCH_SIZE_bytes_total", 0) + pmc[k].get("WRITE_SIZE_bytes_total", 0)
                               for k in keys) / max(1, n_launch)
                 # calibration (profiles/r04_pmc_calibration.txt): FETCH_SIZE counts 64 B per request and a request of a streamed
@@ -493,6 +569,8 @@ def run_workload(args, ctx, light=False):
                        "fora::k_pushq_bin + fora::k_accum<false> (one level / bin pass of the push; k_push_tail finishes the small levels)"
                        if bucketed else "fora::k_push_expand"),
             "launches": int(launches), "avg_launch_ms": avg_ms, "avg_ms_by_kernel": by_kernel,
+            "launch_unit": ("one k_push_team launch + the k_push_tail launch that finishes its slots = the push of one batch" if team else
+                            "one level launch of the bin kernel + its accumulate; a batch's k_push_tail counted as one more launch"),
             "algorithmic_bytes_per_launch": alg_bytes / launches,
             "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation" if bucketed else "24 B per edge relaxation",
             "algorithmic_counts": counts_from,
@@ -503,6 +581,20 @@ def run_workload(args, ctx, light=False):
                             / ((step_ms + tm["push_pop_ms"]) * 1e-3) / 1e9,
                 "ms": step_ms + tm["push_pop_ms"]},
         }
+    if "roofline" in out and ("_fifo_in_run" in out or "_fifo_ratio_file" in out):
+        rf = out["roofline"]
+        alt = {}
+        step_s = rf["push_total"]["ms"] * 1e-3
+        if "_fifo_ratio_file" in out:
+            rp, re = out.pop("_fifo_ratio_file")
+            by = (52.0 * rp * tm["pops"] + 24.0 * re * tm["relax"])
+            alt["ratio_file"] = {"frac": by / step_s / 1e9 / HBM_PEAK_GBS, "counts": "GPU schedule counts x FIFO/GPU ratios of a builder run (profiles/fifo_counts_*.json)"}
+        if "_fifo_in_run" in out:
+            sp, se, sdesc = out.pop("_fifo_in_run")
+            if sp is not None:
+                alt["in_run_sample"] = {"frac": (52.0 * sp + 24.0 * se) * q_timed / step_s / 1e9 / HBM_PEAK_GBS, "counts": sdesc}
+        rf["frac_by_count_source"] = alt
+    out.pop("_fifo_in_run", None); out.pop("_fifo_ratio_file", None)
     walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
     out["phases"] = {
         "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
@@ -522,7 +614,7 @@ def run_workload(args, ctx, light=False):
 # --with_idx, 125 of the 1000 sources) and config 5's (top-k k=500 --opt --with_idx, 125 sources).
 EXTRA_CONFIGS = [
     ("config3_livejournal_with_idx", dict(graph="livejournal", with_idx=True, queries=1000, steps=2, warmup=1)),
-    ("config4_twitter2010_with_idx_one_gpu_share", dict(graph="twitter2010", with_idx=True, queries=125, steps=1, warmup=1)),
+    ("config4_twitter2010_with_idx_one_gpu_share", dict(graph="twitter2010", with_idx=True, queries=125, steps=1, warmup=1, fifo_sample=1)),
     ("config5_twitter2010_topk500_with_idx_one_gpu_share", dict(graph="twitter2010", with_idx=True, topk=500, queries=125, steps=2, warmup=1)),
 ]
 
@@ -538,6 +630,8 @@ def summarize(d):
         e["roofline"] = {k: r[k] for k in ("frac", "achieved", "peak", "unit", "kernel", "launches", "avg_launch_ms", "avg_ms_by_kernel",
                                            "algorithmic_bytes", "algorithmic_counts", "fifo_relaxations_per_query",
                                            "gpu_relaxations_per_query", "traffic", "traffic_upper_bound")}
+        if "frac_by_count_source" in r:
+            e["roofline"]["frac_by_count_source"] = r["frac_by_count_source"]
     ph = d.get("phases", {})
     e["phases_ms_per_step"] = {k: v / max(1, d["steps"]) for k, v in ph.items() if k.endswith("_ms")}
     if "avg_rounds" in d["config"]:

@@ -1088,7 +1088,7 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
     Dev dw = d;
     if (xl) { dw.nbins = (int32_t)d.dg.nbx; dw.acc_xl = d.dg.invb; }
     if (dg) {
-        const size_t lds = (xl ? (size_t)d.dg.H * 8 : 0) + (size_t)3 * d.dg.nrec * 4 + (((size_t)d.dg.nblk + 3) & ~(size_t)3);
+        const size_t lds = (xl ? (size_t)((d.dg.H + 1) & ~1u) * 8 : 0) + (size_t)4 * d.dg.nrec * 4 + (((size_t)d.dg.nblk + 3) & ~(size_t)3); // hub sums | 16-byte records | block -> class bytes
 #define FORA_DG_LAUNCH(NZH, B32, XLF) hipLaunchKernelGGL((k_walk_dg<NZH, B32, XLF>), wgs, dim3(DG_THREADS), lds, c->stream, dw, round)
         const int sel = (nzh ? 4 : 0) | (d.dg.bits32 ? 2 : 0) | (xl ? 1 : 0);
         switch (sel) {
@@ -1620,7 +1620,7 @@ static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col
     // every id from zero_first on must be dangling: degrees descend, so the zero class (if any) is the last one
     uint32_t bits = 1;
     while ((1ull << bits) < (uint64_t)np) bits++;
-    const size_t lds = (size_t)H * 8 + (size_t)3 * nrec * 4 + T.size() + 4;
+    const size_t lds = (size_t)(H + 1) * 8 + (size_t)4 * nrec * 4 + T.size() + 4;
     if (lds > 28 * 1024 || bits > 31) return FORA_OK; // static + dynamic LDS of k_walk_dg stay under 64 KB
     inv.assign((size_t)np, 0);
     for (int32_t v = 0; v < n; v++) inv[perm[(size_t)v]] = (uint32_t)v;

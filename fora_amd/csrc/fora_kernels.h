@@ -2670,13 +2670,15 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
     if (!nitems || *d.err) return;
     const WalkDG &g = d.dg;
-    const uint32_t H = g.H, ts = g.ts;
+    const uint32_t H = g.H, ts = g.ts, nblk1 = g.nblk ? g.nblk - 1 : 0;
     unsigned long long *s_hub = (unsigned long long *)dg_lds64;
-    uint32_t *dg_lds = (uint32_t *)(dg_lds64 + (XL ? H : 0));
-    const uint32_t *s_first = dg_lds, *s_deg = dg_lds + g.nrec, *s_base = dg_lds + 2 * g.nrec;
-    const uint8_t *s_T = (const uint8_t *)(dg_lds + 3 * g.nrec);
-    for (uint32_t i = threadIdx.x; i < 3 * g.nrec; i += DG_THREADS) dg_lds[i] = g.rec[i];
-    for (uint32_t i = threadIdx.x; i < (g.nblk + 3) / 4; i += DG_THREADS) dg_lds[3 * g.nrec + i] = ((const uint32_t *)g.T)[i];
+    uint32_t *dg_lds = (uint32_t *)(dg_lds64 + (XL ? ((H + 1) & ~1u) : 0)); // (whole 16-byte words of hub accumulators)
+    // a record in LDS: (first copy id, out-degree, first edge, -) as ONE 16-byte word -- a move reads it with one ds_read_b128
+    // (rounds 3-4: three arrays, three reads and their addresses per step)
+    uint4 *s_rec = (uint4 *)dg_lds;                       // [nrec]; 16-byte aligned: dg_lds64 is, H * 8 keeps it
+    const uint8_t *s_T = (const uint8_t *)(dg_lds + 4 * g.nrec);
+    for (uint32_t i = threadIdx.x; i < g.nrec; i += DG_THREADS) s_rec[i] = make_uint4(g.rec[i], g.rec[g.nrec + i], g.rec[2 * g.nrec + i], 0u);
+    for (uint32_t i = threadIdx.x; i < (g.nblk + 3) / 4; i += DG_THREADS) dg_lds[4 * g.nrec + i] = ((const uint32_t *)g.T)[i];
     if (XL) for (uint32_t i = threadIdx.x; i < H; i += DG_THREADS) s_hub[i] = 0;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
@@ -2690,10 +2692,11 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     // one move (algo.h:134-140) from copy id `cur` with random word wm
     auto move = [&](uint32_t cur, uint32_t startp, uint32_t wm) -> uint32_t {
-        const bool hub = cur < H;
-        const uint32_t r = hub ? cur : H + s_T[(cur - H) >> ts];
-        const uint32_t dg = s_deg[r];
-        const uint32_t e = s_base[r] + (cur - s_first[r]) * dg + __umulhi(wm, dg);
+        const uint32_t tb = s_T[min((cur - H) >> ts, nblk1)]; // (a hub: cur - H wraps, the index is clamped, the byte unused -- no branch around the read)
+        const uint32_t r = cur < H ? cur : H + tb;
+        const uint4 rc = s_rec[r];
+        const uint32_t dg = rc.y;
+        const uint32_t e = rc.z + (cur - rc.x) * dg + __umulhi(wm, dg);
         const uint32_t nx = dg_colp_at<BITS32>(g, dg ? e : 0u);
         return dg ? nx : startp;
     };

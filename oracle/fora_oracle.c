@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
 #include <string.h>
@@ -396,6 +397,7 @@ typedef struct {
     double rmax, omega, alpha; int opt; uint64_t seed;
     const int32_t *rw_idx; const uint64_t *off, *cnt;
     int tid, threads; double seconds;
+    int cpu; /* >= 0: the worker binds itself to this host CPU before it allocates its buffers */
     int64_t done; uint64_t walks; double elapsed;
 } many_arg;
 static double now_s(void) {
@@ -406,6 +408,12 @@ static double now_s(void) {
 static void *many_worker(void *p) {
     many_arg *a = (many_arg *)p;
     const size_t n = (size_t)a->n;
+    if (a->cpu >= 0) { /* one thread per allowed CPU, first touch of its buffers on that CPU's memory node */
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
     double *reserve = (double *)malloc(sizeof(double) * n), *residue = (double *)malloc(sizeof(double) * n);
     double *ppr = (double *)malloc(sizeof(double) * n);
     int32_t *o1 = (int32_t *)malloc(sizeof(int32_t) * n), *o2 = (int32_t *)malloc(sizeof(int32_t) * n);
@@ -432,6 +440,14 @@ int64_t orc_query_many(int32_t n, const int64_t *row_ptr, const int32_t *col, co
                        double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
                        const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
                        uint64_t *walks) {
+    return orc_query_many_pinned(n, row_ptr, col, sources, nsrc, rmax, omega, alpha, opt, seed, rw_idx, off, cnt, threads, seconds,
+                                 elapsed, walks, NULL, 0);
+}
+/* cpus[0 .. ncpus): host CPUs the threads bind to, thread t -> cpus[t mod ncpus] (NULL: the scheduler places them) */
+int64_t orc_query_many_pinned(int32_t n, const int64_t *row_ptr, const int32_t *col, const int32_t *sources, int64_t nsrc,
+                              double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                              const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
+                              uint64_t *walks, const int32_t *cpus, int ncpus) {
     if (threads < 1) threads = 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     many_arg *args = (many_arg *)calloc((size_t)threads, sizeof(many_arg));
@@ -440,6 +456,7 @@ int64_t orc_query_many(int32_t n, const int64_t *row_ptr, const int32_t *col, co
         a->n = n; a->row_ptr = row_ptr; a->col = col; a->sources = sources; a->nsrc = nsrc;
         a->rmax = rmax; a->omega = omega; a->alpha = alpha; a->opt = opt; a->seed = seed;
         a->rw_idx = rw_idx; a->off = off; a->cnt = cnt; a->tid = t; a->threads = threads; a->seconds = seconds;
+        a->cpu = (cpus && ncpus > 0) ? cpus[t % ncpus] : -1;
         if (pthread_create(&th[t], NULL, many_worker, a) != 0) { threads = t; break; }
     }
     int64_t done = 0;

@@ -104,6 +104,11 @@ int64_t orc_query_many(int32_t n, const int64_t *row_ptr, const int32_t *col, co
                        double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
                        const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
                        uint64_t *walks);
+/* the same with thread t bound to host CPU cpus[t mod ncpus] (bench.py: one thread per CPU the process may run on) */
+int64_t orc_query_many_pinned(int32_t n, const int64_t *row_ptr, const int32_t *col, const int32_t *sources, int64_t nsrc,
+                              double rmax, double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
+                              const uint64_t *off, const uint64_t *cnt, int threads, double seconds, double *elapsed,
+                              uint64_t *walks, const int32_t *cpus, int ncpus);
 int orc_query(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s, double rmax,
               double omega, double alpha, int opt, uint64_t seed, const int32_t *rw_idx,
               const uint64_t *off, const uint64_t *cnt, double *ppr, orc_push_stats *pst,

@@ -220,16 +220,18 @@ def query(g, s, rmax, omega, alpha=0.2, opt=False, seed=0, index=None):
                      n_idx_hit=rs.n_idx_hit, walk_steps=rs.walk_steps)
 
 
-def query_many(g, sources, rmax, omega, threads, seconds, alpha=0.2, opt=False, seed=0, index=None):
+def query_many(g, sources, rmax, omega, threads, seconds, alpha=0.2, opt=False, seed=0, index=None, cpus=None):
     """The query loop on `threads` host threads (pthreads inside the oracle, private buffers per thread) for at most
-    `seconds`: (queries finished, wall seconds, walks)."""
+    `seconds`: (queries finished, wall seconds, walks).  cpus: thread t binds itself to cpus[t mod len(cpus)]."""
     src = np.ascontiguousarray(sources, dtype=np.int32)
     a, b, c = _idx_args(index)
     el, walks = C.c_double(0), C.c_uint64(0)
-    f = lib().orc_query_many
+    f = lib().orc_query_many_pinned
     f.restype = C.c_int64
+    pin = np.ascontiguousarray(cpus, dtype=np.int32) if cpus is not None and len(cpus) else None
     done = f(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), _p(src), C.c_int64(src.size), _d(rmax), _d(omega), _d(alpha),
-             C.c_int(int(opt)), C.c_uint64(seed), a, b, c, C.c_int(int(threads)), _d(seconds), C.byref(el), C.byref(walks))
+             C.c_int(int(opt)), C.c_uint64(seed), a, b, c, C.c_int(int(threads)), _d(seconds), C.byref(el), C.byref(walks),
+             _p(pin), C.c_int(0 if pin is None else int(pin.size)))
     return int(done), float(el.value), int(walks.value)
 
 

@@ -152,6 +152,25 @@ def test_livejournal_with_idx(engine, oracle):
     want, wres, wst = oracle.twin_query(g, int(srcs[0]), rmax, omega, seed=SEED, index=idx)
     assert (res[0] == wres).all() and (ppr[0] == want).all()
     assert st[0]["pops"] == wst["pops"] and st[0]["relax"] == wst["relax"] and st[0]["n_walks"] == wst["n_walks"]
+    # the same source against the REFERENCE-ORDER restatement and against exact PPR, at this size (round 5): the FIFO oracle's
+    # query with the engine's index (f64, pop order of algo.h:980-1017: another valid push state, the same indexed walks for
+    # the nodes both leave residue on) and the f64 power iteration of query.h:1192-1224 on the CPU.  Tolerances: L-inf between
+    # the GPU's and the FIFO oracle's estimates <= 2e-4 (two push states + walk noise; measured ~1e-5), and both inside the
+    # FORA guarantee |est - pi| <= eps * pi for pi >= 1/n (algo.h:455-463) -- the GPU's also against the GPU power iteration.
+    est_gpu = oracle.fix_to_double(ppr[0])
+    est_fifo, fst = oracle.query(g, int(srcs[0]), rmax, omega, seed=SEED, index=idx)
+    assert np.abs(est_gpu - est_fifo).max() <= 2e-4
+    assert abs(float(est_fifo.sum()) - 1.0) < 1e-9
+    exact = oracle.power_iteration(g, int(srcs[0]))                       # CPU, f64, 100 iterations
+    big = exact >= 1.0 / n
+    assert big.sum() > 100
+    rel_gpu = float((np.abs(est_gpu - exact)[big] / exact[big]).max())
+    rel_fifo = float((np.abs(est_fifo - exact)[big] / exact[big]).max())
+    assert rel_gpu <= 0.5 and rel_fifo <= 0.5, (rel_gpu, rel_fifo)        # eps = 0.5
+    gexact, _, _, _ = engine.power_iteration(srcs[:1], max_iter=100)
+    assert np.abs(gexact[0] - exact).max() <= 1e-12
+    print(f"LJ-sized source {int(srcs[0])}: L-inf GPU vs FIFO oracle {np.abs(est_gpu - est_fifo).max():.2e}, worst rel. err on pi >= 1/n: GPU {rel_gpu:.3f}, FIFO {rel_fifo:.3f}")
+    del est_fifo, exact, gexact
     # the whole batch of the config's flavour: stats only (results stay in HBM)
     _, st = engine.query(srcs, with_idx=True, want_ppr=False)
     assert len(st) == 96
