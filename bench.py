@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--balanced", action="store_true", help="--balanced of the reference CLI (query.h:848-884), MI355X cost model")
     ap.add_argument("--balanced-start", type=float, default=1.0, help="first rmax of --balanced as a multiple of rmax (reference: 8)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--fifo-sample-seconds", type=float, default=45.0, help="... and keep sampling until this many seconds are spent")
     ap.add_argument("--fifo-sample", type=int, default=0,
                     help="graphs whose FIFO push is too slow for the CPU legs: run this many sources through the FIFO oracle anyway (push only) "
                          "so that the roofline fraction on in-run counts is printed beside the one on the builder's ratio file")
@@ -476,9 +477,11 @@ def run_workload(args, ctx, light=False):
                 g = O.Graph(n, m, row_ptr, col)
                 pp = pr = pn = 0
                 t1 = time.perf_counter()
-                for s in mine[:args.fifo_sample]:
+                for s in mine:  # sources differ a lot in work (the first one of the bench list is a near-empty push): keep going for the budget
                     ps = O.push_fifo(g, int(s), rmax)
                     pp += ps["pops"]; pr += ps["relax"]; pn += 1
+                    if pn >= args.fifo_sample and time.perf_counter() - t1 > args.fifo_sample_seconds:
+                        break
                 sp, se, sdesc = scale_fifo_counts(pp, pr, pn, last, tm, q_timed)
                 out["_fifo_in_run"] = (sp, se, sdesc + f" ({time.perf_counter() - t1:.0f} s of one core)")
             out["cpu_baseline"] = None

@@ -67,6 +67,8 @@ struct Tunables {
     int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
     int64_t team_coop = 0;       // k_push_team launch: 0 (default) plain launch behind an occupancy check (occupancy x CUs >= grid, team_fits); 1: hipLaunchCooperativeKernel.  Measured on ROCm 7.2 / MI355X (round 5): the cooperative
                                  // launch costs ~9 ms per launch (push of 64 ws-sized queries 14.8 ms against 5.6: the runtime moves the launch to its cooperative queue and back) and a process with two contexts that used it crashed in the runtime's teardown -- opt-in only
+    int64_t topk_bk_div = 16;    // top-k (--opt driver) on wide graphs: message buckets of 1 / this of a query's capacity (plan_workspace); 1: as large as a query's.
+                                 // Twitter-2010-sized, k = 500 --opt --with_idx, 125 sources: 1 -> 245 q/s (8 slots per batch), 8 -> 279 (30), 16 -> 303 (37), 32 -> 304 (41), 64 -> 306 (44); same bits
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -76,7 +78,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -220,6 +222,7 @@ struct fora_ctx {
     fora_ctx *twin = nullptr;
     bool is_twin = false;
     uint32_t bk_scale = 1;        // bucket capacity multiplier, doubled after a bucket overflow (see with_bucket_retry)
+    uint32_t bk_div = 1;          // bucket capacity divisor of the call in progress (top-k: TOPK_BK_DIV on wide graphs, plan_workspace)
     bool bucket_overflow = false; // the last device error was ERR_BUCKET_OVERFLOW
     // --balanced (query.h:848-884): cost model in seconds
     bool balanced = false;
@@ -372,7 +375,11 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
           // `bkcap` option (tests) sets it directly
             const uint64_t total = (uint64_t)(want_wide(c) ? want_bk_cap_wide(c) : want_bk_cap(c));
             uint64_t cap = c->opt_.bkcap > 0 ? total : (total + total / 4 + p.sub - 1) / p.sub;
-            cap = std::min<uint64_t>(cap * c->bk_scale, 1u << 28);
+            // the top-k driver's rounds push from small frontiers (delta starts at 1 / 10k): its buckets start at 1 / bk_div of
+            // a query's -- a slot is a fifth of the memory, a batch holds that many more of them, and every per-round launch
+            // (k_push_tail: ONE workgroup per slot; the slab sweeps; the walk kernels) works on that many more slots at once.
+            // A round that does overflow is run again with doubled buckets like any other (with_bucket_retry)
+            cap = std::min<uint64_t>(std::max<uint64_t>(cap * c->bk_scale / std::max<uint32_t>(1, c->bk_div), 64), 1u << 28);
             p.bk_cap = (uint32_t)((cap + 15) & ~15ull);
         }
         p.segq_cap = n; // frontier positions
@@ -1310,6 +1317,7 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
     }
     const int nl = (int)live_src.size();
     if (nl == 0) return FORA_OK;
+    c->bk_div = 1;
     int rc = ensure_workspace(c, nl, c->omega);
     if (rc) return rc;
     // second lane when there is more than one batch to run
@@ -1853,6 +1861,7 @@ int fora_hip_build_index(fora_ctx *c) {
     HIPCHK(c, hipMemcpy(c->d_idx_off, off.data(), (size_t)c->n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_idx_cnt, cnt.data(), (size_t)c->n * 8, hipMemcpyHostToDevice));
     c->idx_len = total;
+    c->bk_div = 1;
     int rc = ensure_workspace(c, 1, (double)total);
     if (rc) return rc;
     Dev d = make_dev(c, 1, true);
@@ -2022,6 +2031,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
     }
     // omega of the last possible round bounds the walk work list
     const double omega_max = (2 + epsilon) * log(2 / pfail) / min_delta / epsilon / epsilon;
+    c->bk_div = want_wide(c) && c->opt_.bkcap <= 0 ? (uint32_t)std::max<int64_t>(1, c->opt_.topk_bk_div) : 1u;
     int rc = ensure_workspace(c, nq, omega_max);
     if (rc) return rc;
     const uint64_t n = (uint64_t)c->n;
@@ -2169,6 +2179,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
     const double L = log(2 / pfail);
     const long long m = c->m_attr;
     const double omega_max = (2 + epsilon) * L / min_delta / epsilon / epsilon;
+    c->bk_div = 1;
     int rc = ensure_workspace(c, nq, omega_max);
     if (rc) return rc;
     const uint64_t n = (uint64_t)c->n;
@@ -2336,6 +2347,7 @@ static int power_iteration_batch_impl(fora_ctx *c, const int32_t *sources, int n
     for (int i = 0; i < nq; i++)
         if (sources[i] < 0 || sources[i] >= c->n) return fail(c, FORA_E_ARG, "source id out of range");
     HIPCHK(c, hipSetDevice(c->device));
+    c->bk_div = 1;
     int rc = ensure_workspace(c, nq, c->omega);
     if (rc) return rc;
     const uint64_t n = (uint64_t)c->n;
