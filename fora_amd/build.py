@@ -41,6 +41,17 @@ def build_hip(force=False):
     return LIB
 
 
+def build_hip_test(force=False):
+    """The same library with the schedule experiments compiled in (-DFORA_TEST_PATHS=1: threshold rounds, bounded
+    deferral): loaded only by their twin-equivalence tests (tests/conftest.py `engine_test`), never by the CLI or bench."""
+    lib = os.path.join(PKG, "libfora_hip_test.so")
+    srcs = _sources(CSRC, os.path.join(ROOT, "include"))
+    if not force and _newer(lib, srcs):
+        return lib
+    subprocess.run([HIPCC, *HIP_FLAGS, "-DFORA_TEST_PATHS=1", "-shared", "-o", lib, os.path.join(CSRC, "fora_hip.hip")], check=True)
+    return lib
+
+
 def build_cli(force=False):
     host = os.path.join(CSRC, "host")
     if not os.path.isdir(host):
@@ -83,7 +94,10 @@ def build_oracle():
 
 
 def build_all(force=False):
-    build_hip(force)
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(2) as ex:  # the two library builds side by side (hipcc is single-threaded)
+        f1, f2 = ex.submit(build_hip, force), ex.submit(build_hip_test, force)
+        f1.result(); f2.result()
     build_cli(force)
     build_tools(force)
     build_c_smoke(force)

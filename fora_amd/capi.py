@@ -57,9 +57,22 @@ def lib_path():
     return os.environ.get("FORA_HIP_LIB") or os.path.join(_HERE, "libfora_hip.so")
 
 
-def load():
-    """Loads the in-tree HIP library.  Fails loudly when it has not been built."""
+_OTHER = {}
+
+
+def load(path=None):
+    """Loads the in-tree HIP library (path: another build of it -- libfora_hip_test.so, the build with the schedule
+    experiments compiled in, for their twin-equivalence tests).  Fails loudly when it has not been built."""
     global _LIB
+    if path is not None:
+        if path not in _OTHER:
+            if not os.path.exists(path):
+                raise ImportError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            lib = C.CDLL(path)
+            lib.fora_hip_last_error.restype = C.c_char_p
+            lib.fora_hip_destroy.restype = None
+            _OTHER[path] = lib
+        return _OTHER[path]
     if _LIB is None:
         p = lib_path()
         if not os.path.exists(p):
@@ -70,6 +83,9 @@ def load():
     return _LIB
 
 
+TEST_LIB = os.path.join(_HERE, "libfora_hip_test.so")  # -DFORA_TEST_PATHS=1: threshold rounds / bounded deferral compiled in
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -77,8 +93,8 @@ def _p(a):
 class Engine:
     """One GPU context (fora_ctx)."""
 
-    def __init__(self, device=0):
-        self._lib = load()
+    def __init__(self, device=0, lib=None):
+        self._lib = load(lib)
         self._ctx = C.c_void_p()
         rc = self._lib.fora_hip_create(C.c_int(device), C.byref(self._ctx))
         if rc:

@@ -17,6 +17,8 @@
 
 using namespace fora;
 
+struct fora_ctx;
+static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *col); // (defined below, beside set_graph)
 namespace {
 
 struct EvPair {
@@ -145,6 +147,7 @@ struct fora_ctx {
     uint32_t *d_team_ctl = nullptr; // ctl: [0] next slot, [32] abort | sync words | slot sequences
     uint32_t team_n = 0;             // teams of a launch
     bool team_dirty = false;         // a launch ended with an error flag: its reserve accumulators (TeamDev::rsvl) may not be zero
+    bool hub_for_team = false;       // the hub copy was sized for the team path (4096 hubs, k_push_tail its only reader)
     bool team_timeout_seen = false;  // the last device error was ERR_TEAM_TIMEOUT (with_retry runs the call again without the team push)
     int team_suspend = 0;            // calls left that push with the bucketed kernels after a team time-out
     uint64_t team_fallbacks = 0;     // calls re-run that way so far (fora_hip_get_option "team_fallbacks")
@@ -543,6 +546,13 @@ int team_fits(fora_ctx *c);
 int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
     if (!c->n) return fail(c, FORA_E_ARG, "set_graph first");
     if (int rt = ensure_team(c)) return rt;
+    if (!c->is_twin && c->opt_.hubs < 0 && !want_wide(c) && c->hub_for_team != (want_team(c) && c->team_T != 0)) {
+        // the `team` / `team_size` options changed which push this graph takes: the hub copy follows (see build_hub_copy)
+        std::vector<int32_t> col((size_t)std::max<int64_t>(1, c->nnz));
+        HIPCHK(c, hipMemcpy(col.data(), c->d_col, (size_t)c->nnz * 4, hipMemcpyDeviceToHost));
+        free_workspace(c);
+        if (int rh = build_hub_copy(c, c->h_row_ptr.data(), col.data())) return rh;
+    }
     WsPlan p = plan_workspace(c, omega_hint, 1024); // bytes per slot hardly depend on the slot count (sub-bucket rounding)
     const uint64_t n = (uint64_t)c->n;
     // an existing workspace with the same layout is kept if it has enough slots: as many as the call can use, or as
@@ -705,7 +715,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
         d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
         d.tail_hubs = c->opt_.tail_hubs != 0 && (size_t)c->hubs * 8 <= 40960 ? 1u : 0u; // (k_push_tail: 20 KiB of static LDS + the sums within 64 KiB)
     }
-    d.defer_k = c->binned && c->d_dl ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
+    d.defer_k = TEST_PATHS && c->binned && c->d_dl ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
     d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
     d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
     d.dflag[0] = c->d_dflag; d.dflag[1] = c->d_dflag ? c->d_dflag + (size_t)c->B * c->nbins : nullptr;
@@ -837,10 +847,15 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 int h = ev_begin(c, 1);
                 {
                     const size_t hub_lds = dp.col_hub ? (size_t)dp.hubs * 8 : 0;
-                    const bool hub = dp.col_hub != nullptr, split = dp.row_split != nullptr, sched = dp.rounds > 1 || dp.defer_k > 0;
+                    const bool hub = dp.col_hub != nullptr, split = dp.row_split != nullptr, sched = TEST_PATHS && (dp.rounds > 1 || dp.defer_k > 0);
 #define FORA_BIN_LAUNCH(NBV, NT, HUBV, SPLITV, SCHEDV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, SPLITV, SCHEDV>), dim3(xb, nq), dim3(NT), hub_lds, c->stream, dp, L)
+#if FORA_TEST_PATHS
+#define FORA_BIN_SCHED(NBV, NT) FORA_BIN_LAUNCH(NBV, NT, true, true, true)
+#else
+#define FORA_BIN_SCHED(NBV, NT) (void)0
+#endif
 #define FORA_BIN_PICK(NBV, NT) do { \
-                    if (sched) FORA_BIN_LAUNCH(NBV, NT, true, true, true); /* schedule experiments: the everything instantiation */ \
+                    if (sched) FORA_BIN_SCHED(NBV, NT); /* schedule experiments: the everything instantiation (test library only) */ \
                     else if (hub && split) FORA_BIN_LAUNCH(NBV, NT, true, true, false); \
                     else if (hub) FORA_BIN_LAUNCH(NBV, NT, true, false, false); \
                     else if (split) FORA_BIN_LAUNCH(NBV, NT, false, true, false); \
@@ -849,6 +864,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                     else if (d.wide) FORA_BIN_PICK(MAX_BINS_WIDE, BIN_THREADS_WIDE);
                     else FORA_BIN_PICK(MAX_BINS, BLOCK);
 #undef FORA_BIN_PICK
+#undef FORA_BIN_SCHED
 #undef FORA_BIN_LAUNCH
                 }
                 ev_end(c, h);
@@ -857,10 +873,12 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 else hipLaunchKernelGGL((k_accum<false, false>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
                 ev_end(c, h);
             }
-            if (d.rounds > 1) { // threshold rounds: slots whose frontier ran dry move on to the next (halved) threshold
+            if (TEST_PATHS && d.rounds > 1) { // threshold rounds: slots whose frontier ran dry move on to the next (halved) threshold
+#if FORA_TEST_PATHS
                 int h = ev_begin(c, 8);
                 hipLaunchKernelGGL(k_round_sweep, dim3(std::min<uint32_t>(slab_grid_x(c, nq), 32u), nq), dim3(BLOCK), 0, c->stream, d, L);
                 ev_end(c, h);
+#endif
             }
             (void)hipMemcpyAsync(c->h_flc + (size_t)((L + 1) % FLC_RING) * c->B * CSTRIDE, d.fl_count[(L + 1) & 1],
                                  (size_t)nq * 4 * CSTRIDE, hipMemcpyDeviceToHost, c->stream);
@@ -1185,7 +1203,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
     if (c->balanced) {
         rc = push_balanced(c, sources, nq, with_idx);
     } else {
-        if (c->binned) d.rounds = (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.rounds, 1), 16);
+        if (TEST_PATHS && c->binned) d.rounds = (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.rounds, 1), 16);
         d.round_div = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.round_div, 0), 1 << 20);
         const bool team = use_team(c, d);
         h = ev_begin(c, 4);
@@ -1529,6 +1547,7 @@ int fora_hip_device_info(fora_ctx *c, char *arch, int arch_len, int *cus, uint64
 // id order so that the hubs of a bin are a contiguous range, and a copy of col that names them by that number.
 static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *col) {
     (void)row_ptr;
+    dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0; // (a rebuild: ensure_workspace)
     const int32_t n = c->n;
     const int64_t nnz = c->nnz;
     const int64_t wide_auto = nnz <= (1ll << 28) ? 2048 : 0;
@@ -1536,7 +1555,11 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     // wide kernel, 32 KB in the 1024-thread one (its stage of 12 edges per thread takes 122 of the 160 KB)
     const uint64_t nbins_all = bins_of(c);
     const int64_t lds_cap = !want_wide(c) ? 6144 : nbins_all > (uint64_t)MAX_BINS_WIDE ? 4096 : 6144;
-    const int64_t narrow_auto = want_team(c) ? 4096 : 1024;
+    // 4096 only when this graph really takes the team path (ensure_team has built its tables: then the bin kernel never runs
+    // and k_push_tail is the copy's only reader); a graph the team path rejects pushes with the bin kernel, which wants 1024
+    const bool for_team = want_team(c) && c->team_T != 0;
+    c->hub_for_team = for_team;
+    const int64_t narrow_auto = for_team ? 4096 : 1024;
     const int64_t want = std::min<int64_t>(std::max<int64_t>(want_wide(c) ? (c->opt_.hubs_wide < 0 ? wide_auto : c->opt_.hubs_wide) : (c->opt_.hubs < 0 ? narrow_auto : c->opt_.hubs), 0), lds_cap);
     if (want == 0 || nnz == 0 || c->opt_.direct == 1) return FORA_OK;
     if (want_wide(c) && (int64_t)nbins_all > (int64_t)want_pass_bins(c, (int)nbins_all)) return FORA_OK; // several bin passes per level: the passes read the row-sorted copy, hubs are never used (make_dev)
@@ -1735,6 +1758,8 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->n = n; c->m_attr = m_attr; c->nnz = nnz;
     c->dangling_frac = (double)n_dangling / (double)n;
     if (int rc = build_walk_dg(c, row_ptr, col)) return rc;
+    c->team_checked = false;
+    if (int rc = ensure_team(c)) return rc; // (before the hub copy: its size depends on whether the team path takes this graph)
     if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
     return FORA_OK;
 }
@@ -1791,6 +1816,8 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
         if (c->twin) { c->twin->opt_ = c->opt_; c->twin->grid_blocks = c->grid_blocks; }
         return FORA_OK;
     }
+    if (!TEST_PATHS && schedule_option(name) && value != (strcmp(name, "rounds") ? (strcmp(name, "round_div") ? 0 : 4) : 1))
+        return fail(c, FORA_E_ARG, std::string("option ") + name + ": the schedule experiments are not compiled into this library (build with -DFORA_TEST_PATHS=1: libfora_hip_test.so)");
     for (const auto &o : OPTIONS)
         if (!strcmp(name, o.name)) {
             if (c->opt_.*(o.field) == value) return FORA_OK;
@@ -1806,6 +1833,7 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
 int fora_hip_get_option(fora_ctx *c, const char *name, int64_t *value) {
     if (!c || !name || !value) return FORA_E_ARG;
     // read-only state of the engine beside the knobs
+    if (!strcmp(name, "test_paths")) { *value = TEST_PATHS ? 1 : 0; return FORA_OK; } // 1: libfora_hip_test.so (schedule experiments compiled in)
     if (!strcmp(name, "team_fallbacks")) { *value = (int64_t)c->team_fallbacks; return FORA_OK; } // calls re-run with the bucketed push after a team time-out
     if (!strcmp(name, "team_suspended")) { *value = c->team_suspend; return FORA_OK; }             // calls left that do not try the team push
     if (!strcmp(name, "team_members")) { *value = c->team_T; return FORA_OK; }                      // 0: this graph / workspace has no team push

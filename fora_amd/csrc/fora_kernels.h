@@ -25,6 +25,15 @@ namespace fora {
 constexpr int BLOCK = 256;          // 4 wave64 per workgroup
 constexpr uint32_t PUSH_SEG = 256;  // max edges per push work item (bounds hub skew)
 constexpr uint32_t WALK_SEG = 1024; // max walks per walk work item
+// Schedules that were built, measured and lost (threshold rounds -- options rounds / round_div --, bounded
+// deferral -- defer / defer_min) are compiled out of the product library: TEST_PATHS is a compile-time false, the fields
+// they read stay in Dev but are never loaded, and the hot kernels do not carry their registers (round 4: 19 / 16 / 10
+// SGPR spills in k_push_tail / k_walk_online<0> / k_walk_dg).  -DFORA_TEST_PATHS=1 builds them in: libfora_hip_test.so,
+// which the twin-equivalence tests of those schedules load (tests/conftest.py engine_test).
+#ifndef FORA_TEST_PATHS
+#define FORA_TEST_PATHS 0
+#endif
+constexpr bool TEST_PATHS = FORA_TEST_PATHS != 0;
 constexpr uint64_t FIX_ONE = 1ull << 62;
 constexpr uint32_t DEG_SAT = 0xFFFFFFu; // rowinfo low 24 bits: out-degree, saturating
 constexpr int MAX_LEVELS = 1 << 15;
@@ -523,7 +532,7 @@ __global__ void __launch_bounds__(BLOCK) k_init_batch(Dev d, int mode) {
         d.fl[0][(uint64_t)q * d.n] = s;
         d.inc_tab[0][(uint64_t)q * d.segq_cap] = FIX_ONE;
         d.fl_count[0][q * CSTRIDE] = 1;
-        if (mode == 0 && d.rounds > 1) { // threshold rounds: start at t1 << (rounds - 1); the host reads the shift beside the frontier size
+        if (TEST_PATHS && mode == 0 && d.rounds > 1) { // threshold rounds: start at t1 << (rounds - 1); the host reads the shift beside the frontier size
             z.tshift = (uint32_t)d.rounds - 1;
             d.fl_count[0][q * CSTRIDE + 1] = z.tshift;
             d.fl_count[1][q * CSTRIDE + 1] = z.tshift;
@@ -1013,7 +1022,7 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t src = (uint32_t)d.src[q];
-    const int dk = max_levels > 0 ? 0 : d.defer_k; // capped runs (power iteration) keep plain levels
+    const int dk = (!TEST_PATHS || max_levels > 0) ? 0 : d.defer_k; // capped runs (power iteration) keep plain levels
     if (hubmode) for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS) s_hubt[h] = 0;
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
@@ -1269,7 +1278,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
             }
             s_ovn = o;
             uint32_t di = 0;
-            if (!TO_PPR && d.defer_k) { // nodes of this bin deferred by the previous level: they are due now
+            if (TEST_PATHS && !TO_PPR && d.defer_k) { // nodes of this bin deferred by the previous level: they are due now
                 di = d.dflag[par][(uint64_t)q * d.nbins + b];
                 if (di) d.dflag[par][(uint64_t)q * d.nbins + b] = 0;
             }
@@ -1284,15 +1293,15 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     const uint32_t cnt = s_total;
     if (threadIdx.x == 0 && dm) d.qs[q].dang[par] = 0;
     const uint32_t ovn = s_ovn; // entries of the slot's overflow list to scan: 0 unless some belong to THIS bin
-    const bool din = !TO_PPR && s_din != 0;
+    const bool din = TEST_PATHS && !TO_PPR && s_din != 0;
     // hub pre-aggregation (Dev::col_hub): the level's bin kernel summed the increments of this bin's hubs per workgroup
     const bool hubmode = !TO_PPR && d.col_hub && d.fl_count[par][q * CSTRIDE] >= d.hub_min;
     const uint32_t hub_lo = hubmode ? d.hub_first[b] : 0, hub_hi = hubmode ? d.hub_first[b + 1] : 0;
     if (cnt == 0 && dm == 0 && ovn == 0 && !din && hub_hi == hub_lo) return;
-    const int dk = (TO_PPR || !d.defer_k) ? 0 : (d.fl_count[par][q * CSTRIDE] >= d.defer_min ? d.defer_k : 0); // (the level's own frontier size: nothing writes it during the level)
+    const int dk = (!TEST_PATHS || TO_PPR || !d.defer_k) ? 0 : (d.fl_count[par][q * CSTRIDE] >= d.defer_min ? d.defer_k : 0); // (the level's own frontier size: nothing writes it during the level)
     const uint32_t wpb = BSZ / 64; // bitmap words per bin
-    uint64_t *dbm_in = TO_PPR ? nullptr : d.dbm[par] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
-    uint64_t *dbm_out = TO_PPR ? nullptr : d.dbm[par ^ 1] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
+    uint64_t *dbm_in = (!TEST_PATHS || TO_PPR) ? nullptr : d.dbm[par] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
+    uint64_t *dbm_out = (!TEST_PATHS || TO_PPR) ? nullptr : d.dbm[par ^ 1] + (uint64_t)q * d.dbm_words + (uint64_t)b * wpb;
     uint32_t *fl_next = d.fl[par ^ 1] + slab;
     uint64_t *inc_next = TO_PPR ? nullptr : d.inc_tab[par ^ 1] + (uint64_t)q * d.segq_cap;
     uint32_t *flc_next = &d.fl_count[par ^ 1][q * CSTRIDE];
@@ -1580,6 +1589,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
 // headline graph from 1.27x to 1.05x of the sequential FIFO's.  Exit condition and invariants are those of algo.h:1012.
 // grid = (X, nq), after the accumulate of level L.  Every workgroup of a slot takes the same decision: nothing below
 // touches the frontier count before the slot's LAST workgroup is done.
+#if FORA_TEST_PATHS
 __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
     const int q = blockIdx.y;
     const int np = (L & 1) ^ 1;
@@ -1630,6 +1640,7 @@ __global__ void __launch_bounds__(BLOCK) k_round_sweep(Dev d, int L) {
         }
     }
 }
+#endif // FORA_TEST_PATHS
 
 // ------------------------------------------------------------------ walk allocation
 // One thread per (slot, node): num_s_rw and the weight r/num_s_rw, cut into <=WALK_SEG-walk

@@ -59,6 +59,19 @@ def engine():
     e.close()
 
 
+@pytest.fixture(scope="session")
+def engine_test():
+    """The build with the schedule experiments compiled in (libfora_hip_test.so, -DFORA_TEST_PATHS=1): threshold rounds
+    and bounded deferral lost to the plain schedule and are not in the product library; their
+    equivalence with the twin is still checked, against this build."""
+    import fora_amd
+    from fora_amd import capi
+    e = fora_amd.Engine(0, lib=capi.TEST_LIB)
+    assert e.get_option("test_paths") == 1
+    yield e
+    e.close()
+
+
 def pick_sources(g, count, seed, want_dangling=False):
     rng = np.random.Generator(np.random.PCG64(seed))
     deg = g.deg

@@ -475,11 +475,12 @@ def test_team_push_bit_exact(engine, oracle, request, gname, size, tail, xcd, tm
 
 
 @pytest.mark.parametrize("rounds,div", [(1, 0), (2, 0), (3, 0), (5, 0), (2, 4), (2, 2), (3, 4), (4, 1), (3, 1000000)])
-def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds, div):
+def test_threshold_rounds_bit_exact(engine_test, oracle, small_dangling, rounds, div):
     """Threshold rounds of the push (k_round_sweep; options "rounds" and "round_div"): 2^(rounds-1) x the threshold
     first, halved whenever a slot's frontier runs dry (div = 0) or is down to 1/div of the round's largest frontier.
     Every setting equals the twin running the same schedule bit for bit and ends with the exit condition of
     algo.h:1012; rounds that run dry never relax more edges than the plain schedule."""
+    engine = engine_test  # the library build that has these schedules (conftest.py)
     g = small_dangling
     rmax, omega = _load(engine, g, epsilon=0.5)
     srcs = np.concatenate([pick_sources(g, 6, 71), pick_sources(g, 1, 72, want_dangling=True)])
@@ -514,13 +515,14 @@ def test_threshold_rounds_bit_exact(engine, oracle, small_dangling, rounds, div)
 
 @pytest.mark.parametrize("layout", ["narrow", "wide", "wide_multipass", "tail"])
 @pytest.mark.parametrize("k,dmin", [(0, 0), (1, 0), (2, 0), (3, 0), (1, 300), (2, 3000)])
-def test_bounded_deferral_bit_exact(engine, oracle, small_dangling, k, dmin, layout):
+def test_bounded_deferral_bit_exact(engine_test, oracle, small_dangling, k, dmin, layout):
     """Bounded deferral of the push (option "defer", Dev::defer_k): a node that crosses with less than 2^k x its
     threshold waits one level.  Every k equals the twin running the same schedule bit for bit -- in the bitmap form of
     the bucketed levels, the list form of k_push_tail and across the hand-over between them -- ends with the exit
     condition of algo.h:1012, conserves mass exactly, and k = 1 relaxes fewer edges and leaves less residue than plain
     levels (k = 0, the default: the extra levels cost more on the GPU than the edges save).  dmin: only
     levels that pop at least that many nodes defer (option "defer_min")."""
+    engine = engine_test  # the library build that has these schedules (conftest.py)
     g = small_dangling
     if layout in ("wide", "wide_multipass"):
         engine.set_option("force_wide", 1)
@@ -713,3 +715,16 @@ def test_topk_select_compacted_form_same_lists(engine, oracle, small_dangling, m
     # 3 iterations from a source reach few nodes: lists are zero-padded and tie-heavy (equal shares of one push)
     ids, sc = out["1"][2]
     assert (sc[:, -1] == 0).any() or (np.diff(sc, axis=1) == 0).any()
+
+
+def test_schedule_experiments_are_not_in_the_product_library(engine, engine_test):
+    """Threshold rounds and bounded deferral lost to the plain schedule and are compiled out of libfora_hip.so (the hot
+    kernels do not carry their registers); the options exist in libfora_hip_test.so only."""
+    from fora_amd.capi import ForaError
+    assert engine.get_option("test_paths") == 0 and engine_test.get_option("test_paths") == 1
+    for name, v in (("rounds", 2), ("round_div", 2), ("defer", 1), ("defer_min", 5)):
+        with pytest.raises(ForaError) as e:
+            engine.set_option(name, v)
+        assert e.value.code == -1 and "not compiled" in str(e.value)
+    for name, v in (("rounds", 1), ("round_div", 4), ("defer", 0), ("defer_min", 0)):
+        engine.set_option(name, v)  # the defaults are accepted
