@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     __shared__ uint32_t s_hubent;
     __shared__ uint32_t s_hchunks, s_hnext, s_wdone; // chunks the heavy rows have been cut into so far; next one to take; waves done with their own rows
     __shared__ uint32_t s_fill[TEAM_MAX], s_moff[TEAM_MAX];  // next free slot of my bucket (me -> d) in the level's message buffer; its first slot
-    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf, s_nfront;
+    __shared__ uint32_t s_slot, s_F, s_ok, s_ncross, s_nheavy, s_gnext, s_abort, s_rsvovf;
     __shared__ unsigned long long s_dang, s_acc[3];
     (void)kernarg_only;
 
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         uint32_t peak = 0, nlev = 0;
         uint32_t logbase = 0;     // my pops of the slot's levels so far = entries of my reserve log
         bool final_round = false;
-        if (fresh(tid0) == 0) { s_rsvovf = 0; s_nfront = 0; }
+        if (fresh(tid0) == 0) s_rsvovf = 0;
 
 #ifdef FORA_STAMPS_LEVELS
         long long lv_t_ = clock64();
@@ -487,7 +487,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const bool thr_small = (t1 >> 47) == 0;                    // then a 16-bit degree's threshold is two multiplies
                 const uint32_t t1_lo = (uint32_t)t1, t1_hi = (uint32_t)(t1 >> 32);
                 constexpr int SG = 5; // LDS reads in flight together
-                uint32_t nfw = 0;     // crossing nodes this wave has seen
 #pragma unroll
                 for (int g0 = 0; g0 < TEAM_NIT; g0 += SG) {
                     if ((uint32_t)g0 * TEAM_THREADS + (uint32_t)wid * 64u < R) { // (scalar: R is a multiple of 64, a wave's ids are all below it or none is)
@@ -516,13 +515,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                                 }
                                 if (c) crossmask |= 1u << it;
                                 const unsigned long long mk = __ballot(c);
-                                nfw += (uint32_t)__popcll(mk);
                                 if (lane == 0) s_gmask[it * TEAM_NW + wid] = mk; // (group it * 16 + wid < R / 64: not the spare id's)
                             }
                         }
                     }
                 }
-                if (lane == 0 && nfw) atomicAdd(&s_nfront, nfw);
                 if (tid == 0) { // the spare id (the source, if it has no in-edge: only dangling mass ever lands there)
                     const uint64_t rs = res[R];
                     s_gmask[ngroups - 1] = (me == src_owner && rs && rs >= node_thr(t1, src_deg)) ? 1ull : 0ull;
@@ -631,11 +628,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 uint8_t *mark = w_mark[wid];
                 uint32_t npend = 0, gcur = 0, gend = 0; // groups gcur .. gend - 1 of my current draw are not looked at yet
                 bool drained = false;
-                // A wave pops up to 64 nodes at a time -- but when my share of the level's frontier is small, 64 at a time would
-                // leave most waves without work while a few walk through several chunks of edges one after the other (in the levels
-                // of at most 8192 nodes per slot, a fifth of the kernel's time, wave 0 spent a third of its cycles waiting for
-                // those).  A batch is my frontier / 16, at least 4: every wave gets its share, a short one.
-                const uint32_t bsz = min(64u, max(4u, (s_nfront + TEAM_NW - 1) / TEAM_NW));
+                // (Measured in round 5 and dropped: batches of frontier / 16 nodes instead of 64, so that every wave gets a share of a
+                // small level -- 48.6 ms against 47.8; the small levels are bound by their chain of round trips, not by idle waves.)
+                constexpr uint32_t bsz = 64;
                 if (L == 0) { drained = true; if (me == src_owner && wid == 0) { if (lane == 0) list[0] = (uint16_t)src_local; npend = 1; } }
                 for (;;) {
                     while (npend < bsz) { // look at groups until a batch is full (the list holds 128)
@@ -817,7 +812,6 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const TeamArgs a = team_args();
                 uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
                 uint64_t *tout = a->inct + (((uint64_t)team * 2 + (g & 1u)) * T + me) * tstride;
-                if (tid == 0) s_nfront = 0; // (read in the pop phase only, added to in the next sweep: behind two barriers)
                 if (tid == 0 && s_dang) { // one more table entry, one more message
                     const uint32_t ent = s_ncross, pos = atomicAdd(&s_fill[src_owner], 1u);
                     tout[ent] = s_dang;
