@@ -188,12 +188,13 @@ def cpu_all_cores(g, sources, rmax, omega, args, index, threads, host):
         rows.append({"threads": t, "queries": done, "seconds": dt, "value": done / dt})
     top = rows[-1]
     one = rows[0]["value"] if rows[0]["threads"] == 1 else None
-    return {"value": top["value"], "unit": "queries/s", "cores": host["physical_cores_allowed"], "threads": threads, "kind": "port",
+    return {"value": top["value"], "unit": "queries/s", "cores": min(host["physical_cores_allowed"], threads), "threads": threads, "kind": "port",
             "sample": f"{top['queries']} of the bench sources over {threads} pinned pthreads (sources tid mod T, private buffers), {top['seconds']:.1f} s",
             "scaling": rows, "speedup_over_one_thread": (top["value"] / one) if one else None,
             "host": {k: v for k, v in host.items() if k != "bind_order"},
             "note": "every thread runs whole queries (a webstanford-sized query is 6.5 M scattered 8-byte read-modify-writes and 16 M "
-                    "dependent walk steps over ~11 MB of private arrays); cores = physical cores the process may use, threads = pthreads started"}
+                    "dependent walk steps over ~11 MB of private arrays); cores = physical cores the threads run on (one pinned thread per core up to the "
+                    "cgroup's CPU quota), threads = pthreads started; host.* = what the box has and what the process may use"}
 
 
 def accuracy(eng, g, sources, n, m, args, np):
