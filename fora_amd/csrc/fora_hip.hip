@@ -225,6 +225,7 @@ struct fora_ctx {
     fora_ctx *twin = nullptr;
     bool is_twin = false;
     uint32_t bk_scale = 1;        // bucket capacity multiplier, doubled after a bucket overflow (see with_bucket_retry)
+    uint64_t bucket_retries = 0;  // calls re-run with doubled buckets so far (fora_hip_get_option "bucket_retries")
     uint32_t bk_div = 1;          // bucket capacity divisor of the call in progress (top-k: TOPK_BK_DIV on wide graphs, plan_workspace)
     bool bucket_overflow = false; // the last device error was ERR_BUCKET_OVERFLOW
     // --balanced (query.h:848-884): cost model in seconds
@@ -1457,6 +1458,7 @@ template <class F> int with_bucket_retry(fora_ctx *c, F call) {
             return rc;
         }
         c->bk_scale *= 2;
+        c->bucket_retries++;
         c->bucket_overflow = false;
         forget_attempt(t0);
         if (c->twin) {
@@ -1834,6 +1836,7 @@ int fora_hip_get_option(fora_ctx *c, const char *name, int64_t *value) {
     if (!c || !name || !value) return FORA_E_ARG;
     // read-only state of the engine beside the knobs
     if (!strcmp(name, "test_paths")) { *value = TEST_PATHS ? 1 : 0; return FORA_OK; } // 1: libfora_hip_test.so (schedule experiments compiled in)
+    if (!strcmp(name, "bucket_retries")) { *value = (int64_t)c->bucket_retries; return FORA_OK; } // re-runs with doubled message buckets
     if (!strcmp(name, "team_fallbacks")) { *value = (int64_t)c->team_fallbacks; return FORA_OK; } // calls re-run with the bucketed push after a team time-out
     if (!strcmp(name, "team_suspended")) { *value = c->team_suspend; return FORA_OK; }             // calls left that do not try the team push
     if (!strcmp(name, "team_members")) { *value = c->team_T; return FORA_OK; }                      // 0: this graph / workspace has no team push

@@ -148,7 +148,8 @@ int fora_hip_set_option(fora_ctx *ctx, const char *name, int64_t value);
  * hipLaunchCooperativeKernel -- option team_coop, off by default), "team_fallbacks" (calls that were run again through the bucketed push because a team of
  * k_push_team timed out waiting for a member -- its workgroups were not co-resident, e.g. another context's kernels held
  * CUs; the caller sees FORA_OK and the same result bits), "team_suspended" (calls left that do not try the team push
- * after such a time-out). */
+ * after such a time-out), "bucket_retries" (calls that were run again with doubled message buckets), "test_paths" (1: the build
+ * with the schedule experiments compiled in, libfora_hip_test.so). */
 int fora_hip_get_option(fora_ctx *ctx, const char *name, int64_t *value);
 
 /* ---- walk index: replaces build() (build.h:302-366), rw_idx / rw_idx_info

@@ -108,6 +108,42 @@ def test_bucket_overflow_is_retried_with_larger_buckets(engine, oracle, small, m
     engine.set_graph(g.n, g.m, g.row_ptr, g.col)   # a new graph starts from the default capacity again
 
 
+def test_topk_small_buckets_overflow_is_retried(engine, oracle, small):
+    """The top-k driver plans its message buckets at 1 / topk_bk_div of a query's on graphs of the wide layout (round 5: 37
+    instead of 8 Twitter-2010-sized slots per batch).  With a divisor far too large the buckets (and the overflow list)
+    overflow in the later rounds: the call doubles them and runs again by itself; ids, scores and rounds are the twin's."""
+    g = small
+    engine.set_option("force_wide", 1)
+    engine.set_option("tail", 0)          # every level through the bucketed kernels
+    engine.set_option("ovcap", 1024)      # (the wide layout sends increments >= 2^50 through this list: not much smaller)
+    engine.set_option("xb", 1)            # one sub-bucket per (slot, bin)
+    engine.set_option("topk_bk_div", 1 << 10)
+    try:
+        engine.clear_index()
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+        engine.set_params(epsilon=0.5, opt=True, seed=SEED)
+        srcs = pick_sources(g, 3, 311)
+        r0 = engine.get_option("bucket_retries")
+        ids, sc, rounds = engine.topk(srcs, 100, epsilon=0.5)
+        assert engine.get_option("bucket_retries") > r0   # the buckets did overflow and the call was run again
+        for i, s in enumerate(srcs):
+            wid, wsc, wr, _ = oracle.twin_topk_query(g, int(s), 100, 0.5, seed=SEED)
+            assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+        # the default divisor on the same (forced wide) layout: same bits, no retry needed
+        engine.set_option("topk_bk_div", 16)
+        engine.set_option("xb", 0)
+        engine.set_option("ovcap", 0)
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)  # (back to the default capacity)
+        engine.set_params(epsilon=0.5, opt=True, seed=SEED)
+        r1 = engine.get_option("bucket_retries")
+        ids2, sc2, rounds2 = engine.topk(srcs, 100, epsilon=0.5)
+        assert engine.get_option("bucket_retries") == r1
+        assert (ids2 == ids).all() and (sc2 == sc).all() and (rounds2 == rounds).all()
+    finally:
+        engine.reset_options()
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+
+
 def test_c_binding_runs_end_to_end():
     """INTEGRATION.md's call sequence, compiled as C and linked against libfora_hip.so, on the GPU."""
     import os
