@@ -57,6 +57,9 @@ constexpr int TEAM_NIT = (TEAM_R_CAP + TEAM_THREADS - 1) / TEAM_THREADS; // swee
 #ifndef FORA_TEAM_CU
 #define FORA_TEAM_CU 4
 #endif
+#ifndef FORA_TEAM_MPL
+#define FORA_TEAM_MPL 2 // messages a lane consumes per load: 2 (one 8-byte load); 4 (one 16-byte load through inline asm, 256-message segments) measured 46.7 against 45.8 ms
+#endif
 #ifndef FORA_TEAM_DRAW
 #define FORA_TEAM_DRAW 4 // 64-id groups a wave draws at a time
 #endif
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     const int tid0 = threadIdx.x;
     const int tid = tid0, lane = tid & 63, wid = tid >> 6;
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
-    uint32_t dgp[(TEAM_NIT + 1) / 2];
+    uint32_t dgp[(TEAM_NIT + 1) / 2], thh[TEAM_NIT];
     bool same_xcd;
     {
         const TeamArgs a = team_args();
@@ -272,8 +275,14 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
 #pragma unroll
         for (int it = 0; it < TEAM_NIT; it++) { // (R is a multiple of 64: a wave's 64 ids are all below R or none is)
             const uint32_t l = it * TEAM_THREADS + tid;
-            const uint32_t dv = (it * TEAM_THREADS + wbase < R) ? (uint32_t)deg16[l] : 0u;
+            const bool in = it * TEAM_THREADS + wbase < R;
+            const uint32_t dv = in ? (uint32_t)deg16[l] : 0u;
             if (it & 1) dgp[it >> 1] |= dv << 16; else dgp[it >> 1] = dv;
+            // ... and the HIGH WORD of its threshold (algo.h:1012: t1 x out-degree, the exact degree for a hub): the sweep compares
+            // a residue's high word with it and only looks closer when the two are equal
+            uint32_t dx = dv;
+            if (in && dv == 0xFFFFu) dx = a->deg[a->l2n[(uint64_t)me * R + l]];
+            thh[it] = in ? (uint32_t)(node_thr(a->t1, dx) >> 32) : 0xFFFFFFFFu;
         }
         // Do the team's members share an XCD?  Each adds 1 to the byte of its XCC id (HW_REG_XCC_ID) in the census word and
         // waits for all T.  Members of one XCD share its L2: what a member has stored (and waited for: vmcnt(0)) is in that L2,
@@ -408,15 +417,20 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const bool mine = (ready >> lane) & 1ull;
                 const uint32_t c = mine ? (uint32_t)wv & 0xFFFFFFu : 0u; // lane s: the messages source s has for me
                 fsum += mine ? (uint32_t)(wv >> 24) & 0xFFFFu : 0u;
-                const uint32_t ns = (c + 127u) >> 7;
+                // a lane takes MPL consecutive messages of a segment: 2 = one 8-byte load (default); 4 = one 16-byte load and half the
+                // load instructions, measured slower (the wait for the asm loads serialises the trip; 256-message segments); CU segments per trip
+                constexpr int MPL = FORA_TEAM_MPL, SEGSH = MPL == 4 ? 8 : 7;
+                constexpr int CU = MPL == 4 ? (FORA_TEAM_CU + 1) / 2 : FORA_TEAM_CU;
+                const uint32_t ns = (c + (1u << SEGSH) - 1u) >> SEGSH;
                 const uint32_t r0 = ((uint32_t)wid + 2u * TEAM_NW - (uint32_t)lane % TEAM_NW) % TEAM_NW; // my first segment of source `lane`
                 const uint32_t kmine = ns > r0 ? (ns - r0 + TEAM_NW - 1) / TEAM_NW : 0u;
                 uint32_t nmine;
                 const uint32_t pmine = wave_excl_scan(kmine, nmine);
-                constexpr int CU = FORA_TEAM_CU;
                 for (uint32_t i0 = 0; i0 < nmine; i0 += CU) {
-                    uint2 m[CU];
+                    uint32_t mw[CU][MPL];
+                    uint4 mq[CU];
                     uint32_t srcm[CU], left[CU];
+                    const uint32_t *mp[CU];
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         const bool have = i0 + k < nmine;              // (wave-uniform)
@@ -424,37 +438,49 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const uint32_t sidx = (uint32_t)__popcll(__ballot(pmine <= ic)) - 1u; // the last source whose segments start at or before my ic-th (lanes >= T: pmine = nmine > ic)
                         const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)r0, (int)sidx) + (ic - (uint32_t)__builtin_amdgcn_readlane((int)pmine, (int)sidx)) * TEAM_NW;
                         const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)sidx);
-                        const uint32_t idx = (j << 7) + 2u * lane;
-                        left[k] = (have && idx < n_s) ? n_s - idx : 0u; // messages of this lane's pair that exist (0, 1, or more = 2)
+                        const uint32_t idx = (j << SEGSH) + (uint32_t)MPL * lane;
+                        left[k] = (have && idx < n_s) ? n_s - idx : 0u; // messages of this lane's group that exist (0 .. MPL, or more = MPL)
                         srcm[k] = sidx;
-                        {
-                            const unsigned long long *mp = (const unsigned long long *)(min_ + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)coffv, (int)sidx) + (left[k] ? idx : 0u)); // (buckets hold a multiple of 16 words)
-                            const unsigned long long mm = __hip_atomic_load(mp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            m[k].x = (uint32_t)mm; m[k].y = (uint32_t)(mm >> 32);
+                        mp[k] = min_ + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)coffv, (int)sidx) + (left[k] ? idx : 0u); // (buckets start on and hold a multiple of 16 words)
+                        if (MPL != 4) {
+                            const unsigned long long mm = __hip_atomic_load((const unsigned long long *)mp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            mw[k][0] = (uint32_t)mm; mw[k][1] = (uint32_t)(mm >> 32);
                         }
                     }
-                    uint64_t va[CU], vb[CU];
+                    if (MPL == 4) {
+                        // 16-byte loads past the L1 (sc1, like every load of handed-over data).  The compiler neither issues nor counts
+                        // them: loads and the wait for them are ONE asm statement, nothing reads a destination register before it
+                        static_assert(MPL != 4 || CU <= 2, "one asm statement per trip");
+                        if (CU == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(mq[0]) : "v"(mp[0]) : "memory");
+                        else asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                          : "=&v"(mq[0]), "=&v"(mq[CU - 1]) : "v"(mp[0]), "v"(mp[CU - 1]) : "memory");
+#pragma unroll
+                        for (int k = 0; k < CU; k++) { mw[k][0] = mq[k].x; mw[k][1] = mq[k].y; mw[k][MPL - 2] = mq[k].z; mw[k][MPL - 1] = mq[k].w; }
+                    }
+                    uint64_t vv[CU][MPL];
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
-                        const unsigned long long *pa = (const unsigned long long *)&tb[left[k] ? (m[k].x >> TEAM_LBITS) : 0u], *pb = (const unsigned long long *)&tb[left[k] > 1 ? (m[k].y >> TEAM_LBITS) : 0u];
-                        va[k] = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vb[k] = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < MPL; u++)
+                            vv[k][u] = __hip_atomic_load((const unsigned long long *)&tb[left[k] > (uint32_t)u ? (mw[k][u] >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #ifdef FORA_PROBE_GATHER // what does ONE MORE scattered 8-byte gather per message cost?  (another line of the same table; adds 0)
 #pragma unroll
                     for (int k = 0; k < CU; k++) {
                         const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
-                        const uint64_t xa = __hip_atomic_load((const unsigned long long *)&tb[left[k] ? ((m[k].x >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint64_t xb = __hip_atomic_load((const unsigned long long *)&tb[left[k] > 1 ? ((m[k].y >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        va[k] += xa >> 63; vb[k] += xb >> 63; // (values are below 2^62)
+#pragma unroll
+                        for (int u = 0; u < MPL; u++) {
+                            const uint64_t xa = __hip_atomic_load((const unsigned long long *)&tb[left[k] > (uint32_t)u ? ((mw[k][u] >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            vv[k][u] += xa >> 63; // (values are below 2^62)
+                        }
                     }
 #endif
 #pragma unroll
-                    for (int k = 0; k < CU; k++) {
-                        if (left[k] && va[k]) atomicAdd((unsigned long long *)&res[m[k].x & TEAM_LMASK], (unsigned long long)va[k]);
-                        if (left[k] > 1 && vb[k]) atomicAdd((unsigned long long *)&res[m[k].y & TEAM_LMASK], (unsigned long long)vb[k]);
-                    }
+                    for (int k = 0; k < CU; k++)
+#pragma unroll
+                        for (int u = 0; u < MPL; u++)
+                            if (left[k] > (uint32_t)u && vv[k][u]) atomicAdd((unsigned long long *)&res[mw[k][u] & TEAM_LMASK], (unsigned long long)vv[k][u]);
                 }
                 } // (sources that were through at this look)
                 if (wid == 0) {
@@ -501,7 +527,9 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                             const int it = g0 + k;
                             if ((uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R) { // scalar
                                 bool c = false;
-                                if (r[k]) {
+                                const uint32_t rhi = (uint32_t)(r[k] >> 32);
+                                if (rhi > thh[it]) c = true; // (most ids: one compare says no, a second says yes)
+                                else if (rhi == thh[it] && r[k]) { // the high words agree (or the node is dangling: threshold 1): the whole product
                                     uint32_t dg = (dgp[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu;
                                     asm volatile("" : "+v"(dg)); // (or the compiler keeps fifteen 64-bit thresholds per thread across the levels -- and spills them)
                                     if (dg == 0xFFFFu) { // a hub: its exact degree
