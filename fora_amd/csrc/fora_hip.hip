@@ -19,6 +19,7 @@ using namespace fora;
 
 struct fora_ctx;
 static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *col); // (defined below, beside set_graph)
+static int build_quad_copies(fora_ctx *c);
 namespace {
 
 struct EvPair {
@@ -71,6 +72,7 @@ struct Tunables {
                                  // launch costs ~9 ms per launch (push of 64 ws-sized queries 14.8 ms against 5.6: the runtime moves the launch to its cooperative queue and back) and a process with two contexts that used it crashed in the runtime's teardown -- opt-in only
     int64_t topk_bk_div = 16;    // top-k (--opt driver) on wide graphs: message buckets of 1 / this of a query's capacity (plan_workspace); 1: as large as a query's.
                                  // Twitter-2010-sized, k = 500 --opt --with_idx, 125 sources: 1 -> 245 q/s (8 slots per batch), 8 -> 279 (30), 16 -> 303 (37), 32 -> 304 (41), 64 -> 306 (44); same bits
+    int64_t quads = 1;           // wide layouts, one bin pass per level: k_pushq_bin reads quad-padded copies of col / col_hub with 16-byte loads (0: single edges, round 4)
     int64_t pipeline = 0;        // 1: second lane (stream + workspace) when a call has more than one batch
     int64_t profile = 1;         // 0: no HIP event pairs around the launches
     int64_t grid = 2048;         // workgroups of the direct-path kernels
@@ -80,7 +82,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -121,6 +123,9 @@ struct fora_ctx {
     uint32_t colbits = 0;
     // degree-grouped walk copy (WalkDG): device arrays + the scalars of the struct; dg.colp == nullptr: none
     int32_t *d_col_hub = nullptr;    // hub pre-aggregation (Dev::col_hub)
+    int32_t *d_col4 = nullptr, *d_col_hub4 = nullptr; // quad-padded copies for the wide bin kernel (Dev::col4); null: not built
+    uint64_t *d_rowinfo4 = nullptr;
+    uint64_t quads = 0;              // quads of the padded copies
     uint32_t *d_hub_node = nullptr, *d_hub_first = nullptr;
     uint32_t hubs = 0;
     int hub_shift = 0;               // bin shift the hub ranges were built for
@@ -266,6 +271,7 @@ template <typename T> void dfree(T *&p) {
 void free_graph(fora_ctx *c) {
     dfree(c->d_row_ptr); dfree(c->d_col); dfree(c->d_rowinfo); dfree(c->d_deg); dfree(c->d_rp32); dfree(c->d_colp); dfree(c->d_col_push); dfree(c->d_row_split);
     dfree(c->d_col_hub); dfree(c->d_hub_node); dfree(c->d_hub_first); c->hubs = 0;
+    dfree(c->d_col4); dfree(c->d_col_hub4); dfree(c->d_rowinfo4); c->quads = 0;
     dfree(c->d_colt); dfree(c->d_team_rowq); dfree(c->d_team_off); dfree(c->d_team_n2l); dfree(c->d_team_l2n); dfree(c->d_team_deg16); dfree(c->d_team_rowl); dfree(c->d_team_hubtgt); c->team_H = 0; c->team_T = 0; c->team_R = 0; c->team_cap = 0; c->team_checked = false;
     dfree(c->d_dg_perm); dfree(c->d_dg_inv); dfree(c->d_dg_colp); dfree(c->d_dg_rec); dfree(c->d_dg_T); dfree(c->d_dg_invb);
     c->dg = WalkDG{};
@@ -553,6 +559,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
         HIPCHK(c, hipMemcpy(col.data(), c->d_col, (size_t)c->nnz * 4, hipMemcpyDeviceToHost));
         free_workspace(c);
         if (int rh = build_hub_copy(c, c->h_row_ptr.data(), col.data())) return rh;
+        if (int rq = build_quad_copies(c)) return rq;
     }
     WsPlan p = plan_workspace(c, omega_hint, 1024); // bytes per slot hardly depend on the slot count (sub-bucket rounding)
     const uint64_t n = (uint64_t)c->n;
@@ -716,6 +723,11 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
         d.hub_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.hub_min, 1), 0x7FFFFFFF);
         d.tail_hubs = c->opt_.tail_hubs != 0 && (size_t)c->hubs * 8 <= 40960 ? 1u : 0u; // (k_push_tail: 20 KiB of static LDS + the sums within 64 KiB)
     }
+    if (d.wide && c->d_col4 && !c->d_row_split && !c->d_col_push && c->opt_.quads != 0) { // one bin pass per level: the bin kernel reads quads
+        d.col4 = c->d_col4; d.rowinfo4 = c->d_rowinfo4;
+        d.col_hub4 = d.col_hub ? c->d_col_hub4 : nullptr;
+        if (d.col_hub && !d.col_hub4) d.col4 = nullptr; // (no padded hub copy: edges one by one)
+    }
     d.defer_k = TEST_PATHS && c->binned && c->d_dl ? (int32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer, 0), 8) : 0; // the direct path keeps plain levels
     d.defer_min = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.defer_min, 0), 0x7FFFFFFF);
     d.dbm[0] = c->d_dbm; d.dbm[1] = c->d_dbm ? c->d_dbm + (size_t)c->B * c->dbm_words : nullptr; d.dbm_words = c->dbm_words;
@@ -855,7 +867,9 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
 #else
 #define FORA_BIN_SCHED(NBV, NT) (void)0
 #endif
+#define FORA_BIN_QUAD(NBV, NT, HUBV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, false, false, true>), dim3(xb, nq), dim3(NT), hub_lds, c->stream, dp, L)
 #define FORA_BIN_PICK(NBV, NT) do { \
+                    if (!sched && !split && dp.col4 && NBV > MAX_BINS) { if (hub) FORA_BIN_QUAD(NBV, NT, true); else FORA_BIN_QUAD(NBV, NT, false); break; } \
                     if (sched) FORA_BIN_SCHED(NBV, NT); /* schedule experiments: the everything instantiation (test library only) */ \
                     else if (hub && split) FORA_BIN_LAUNCH(NBV, NT, true, true, false); \
                     else if (hub) FORA_BIN_LAUNCH(NBV, NT, true, false, false); \
@@ -865,6 +879,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                     else if (d.wide) FORA_BIN_PICK(MAX_BINS_WIDE, BIN_THREADS_WIDE);
                     else FORA_BIN_PICK(MAX_BINS, BLOCK);
 #undef FORA_BIN_PICK
+#undef FORA_BIN_QUAD
 #undef FORA_BIN_SCHED
 #undef FORA_BIN_LAUNCH
                 }
@@ -1292,6 +1307,7 @@ int sync_twin(fora_ctx *c) {
     w->dg = c->dg; // arrays owned by c
     w->d_col_hub = c->d_col_hub; w->d_hub_node = c->d_hub_node; w->d_hub_first = c->d_hub_first; w->hubs = c->hubs; w->hub_shift = c->hub_shift;
     w->d_col_push = c->d_col_push; w->d_row_split = c->d_row_split; w->split_pbins = c->split_pbins; // shared, owned by c
+    w->d_col4 = c->d_col4; w->d_col_hub4 = c->d_col_hub4; w->d_rowinfo4 = c->d_rowinfo4; w->quads = c->quads;
     w->d_colt = c->d_colt; w->d_team_rowq = c->d_team_rowq; w->d_team_off = c->d_team_off; w->d_team_n2l = c->d_team_n2l; w->d_team_l2n = c->d_team_l2n; w->d_team_deg16 = c->d_team_deg16; w->d_team_rowl = c->d_team_rowl; w->d_team_hubtgt = c->d_team_hubtgt; w->team_H = c->team_H; w->team_T = c->team_T; w->team_R = c->team_R; w->team_cap = c->team_cap; w->dangling_frac = c->dangling_frac;
     w->have_params = c->have_params; w->alpha = c->alpha; w->epsilon = c->epsilon; w->rmax_scale = c->rmax_scale;
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
@@ -1596,6 +1612,38 @@ static int build_hub_copy(fora_ctx *c, const int64_t *row_ptr, const int32_t *co
     return FORA_OK;
 }
 
+// Quad-padded copies of col (and of the hub copy) for the wide bin kernel (Dev::col4), built on the device from what
+// set_graph has uploaded; only for graphs that run the wide layout in one bin pass per level.
+static int build_quad_copies(fora_ctx *c) {
+    dfree(c->d_col4); dfree(c->d_col_hub4); dfree(c->d_rowinfo4); c->quads = 0;
+    if (!want_binned(c) || !want_wide(c) || c->nnz == 0 || c->opt_.quads == 0) return FORA_OK;
+    const uint64_t nbins_all = bins_of(c);
+    if ((int64_t)nbins_all > (int64_t)want_pass_bins(c, (int)nbins_all)) return FORA_OK; // several passes per level: pass-split rows, edge by edge
+    const size_t n = (size_t)c->n;
+    std::vector<uint64_t> ri4(n);
+    uint64_t q = 0;
+    for (size_t v = 0; v < n; v++) {
+        const uint64_t dg = (uint64_t)(c->h_row_ptr[v + 1] - c->h_row_ptr[v]);
+        ri4[v] = (q << 24) | std::min<uint64_t>(dg, DEG_SAT);
+        q += (dg + 3) / 4;
+    }
+    if (q >= (1ull << 40)) return FORA_OK;
+    HIPCHK(c, hipMalloc(&c->d_rowinfo4, n * 8));
+    HIPCHK(c, hipMemcpy(c->d_rowinfo4, ri4.data(), n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_col4, std::max<uint64_t>(1, q) * 16));
+    const unsigned grid = (unsigned)std::min<size_t>((n + BLOCK - 1) / BLOCK, 1u << 20);
+    hipLaunchKernelGGL(k_pad_quads, dim3(grid), dim3(BLOCK), 0, c->stream, c->n, (const int64_t *)c->d_row_ptr, (const int32_t *)c->d_col,
+                       (const uint64_t *)c->d_rowinfo4, c->d_col4);
+    if (c->d_col_hub) {
+        HIPCHK(c, hipMalloc(&c->d_col_hub4, std::max<uint64_t>(1, q) * 16));
+        hipLaunchKernelGGL(k_pad_quads, dim3(grid), dim3(BLOCK), 0, c->stream, c->n, (const int64_t *)c->d_row_ptr, (const int32_t *)c->d_col_hub,
+                           (const uint64_t *)c->d_rowinfo4, c->d_col_hub4);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->quads = q;
+    return FORA_OK;
+}
+
 // Degree-grouped walk copy (WalkDG, fora_kernels.h) of graphs that run the narrow layout: H hub records + at most 255
 // out-degree classes whose tables fit a workgroup's LDS share.  Graphs that do not qualify keep k_walk_online.
 static int build_walk_dg(fora_ctx *c, const int64_t *row_ptr, const int32_t *col) {
@@ -1763,6 +1811,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     c->team_checked = false;
     if (int rc = ensure_team(c)) return rc; // (before the hub copy: its size depends on whether the team path takes this graph)
     if (int rc = build_hub_copy(c, row_ptr, col)) return rc;
+    if (int rc = build_quad_copies(c)) return rc;
     return FORA_OK;
 }
 

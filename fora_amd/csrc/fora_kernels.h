@@ -240,6 +240,12 @@ struct Dev {
     // indices follow the node ids, so the hubs of one bin are a contiguous range [hub_first[b], hub_first[b + 1]).
     // Integer adds commute: same bits as the plain messages.
     const int32_t *col_hub;    // [nnz] or null
+    // Quad copies for the wide bin kernel (round 5): col / col_hub with every row padded with -1 words to whole quads (16-byte
+    // aligned) and rowinfo4 = (first QUAD of the row << 24) | min(outdeg, DEG_SAT): a lane of k_pushq_bin<.., QUAD> reads four
+    // consecutive edges with ONE 16-byte load (a vector memory instruction costs the CU's address path the same whatever it
+    // carries).  Null: the kernel reads single edges (narrow layout, several bin passes per level).
+    const int32_t *col4, *col_hub4;
+    const uint64_t *rowinfo4;
     const uint32_t *hub_node;  // [hubs] node id of hub h
     const uint32_t *hub_first; // [nbins + 1]
     uint64_t *hubsum;          // [slot][sub][hubs]
@@ -730,8 +736,9 @@ __global__ void __launch_bounds__(BLOCK) k_push_expand(Dev d, int L) {
 // loading the entries one or two tiles ahead -- the kernel is bound by its instruction and LDS mix, not by these waits.
 // HUB: the graph has a hub copy (Dev::col_hub); SPLIT: several bin passes per level over row-split offsets; ROUNDS: threshold
 // rounds / bounded deferral bookkeeping.  The plain instantiation does not carry what it does not use (spills).
-template <int NB, bool HUB, bool SPLIT, bool SCHED>
+template <int NB, bool HUB, bool SPLIT, bool SCHED, bool QUAD = false>
 __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int L) {
+    static_assert(!(QUAD && SPLIT), "pass-split rows are read edge by edge");
     constexpr int NT = BinThreads<NB>::value; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
     const int q = blockIdx.y;
     const int par = L & 1;
@@ -751,7 +758,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     extern __shared__ unsigned long long s_hub[]; // [d.hubs] when hubmode
     const bool hubmode = HUB && d.col_hub && count >= d.hub_min;
     if (hubmode) for (uint32_t i = threadIdx.x; i < d.hubs; i += BinThreads<NB>::value) s_hub[i] = 0;
-    const int32_t *colsrc = hubmode ? d.col_hub : d.col_push;
+    const int32_t *colsrc = QUAD ? (hubmode ? d.col_hub4 : d.col4) : (hubmode ? d.col_hub : d.col_push);
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target: 13 narrow, 14 in the wide layouts
     constexpr uint32_t BSZ = 1u << BS;
     constexpr int SRC_BITS = NT == 256 ? 8 : NT == 512 ? 9 : 10;
@@ -801,9 +808,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         if (i < count) {
             const uint32_t v = in[i];
             uint64_t inc = incs[i]; // first pass: the residue taken from v; later passes: its increment
-            const uint64_t ri = d.rowinfo[v];
-            int64_t beg = (int64_t)(ri >> 24);
-            uint32_t deg = ri_deg(d, ri, v);
+            const uint64_t ri = QUAD ? d.rowinfo4[v] : d.rowinfo[v];
+            int64_t beg = (int64_t)(ri >> 24); // QUAD: the row's first quad
+            uint32_t deg = QUAD ? (((uint32_t)ri & DEG_SAT) == DEG_SAT ? (uint32_t)(d.row_ptr[v + 1] - d.row_ptr[v]) : (uint32_t)ri & DEG_SAT) : ri_deg(d, ri, v);
             if (first_pass) { // pop (algo.h:983-1002): the residue word itself was zeroed when v entered the list
                 const uint64_t rsv_old = d.ppr[slab + v];
                 uint64_t rsv_add, dang;
@@ -820,6 +827,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             s_ebeg[threadIdx.x] = beg;
             s_inc[threadIdx.x] = inc;
             cnt = inc ? deg : 0u; // an increment of zero changes nothing: skip the row
+            if (QUAD) cnt = (cnt + 3u) >> 2; // the tile's rows are concatenated quad by quad
         }
         uint32_t total;
         const uint32_t pre = block_excl_scan_n<NT>(cnt, s_w, total);
@@ -828,8 +836,43 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         __syncthreads();
         STAMP(0);
         // ---- bin the tile's edges
-        for (uint32_t cb = 0; cb < total; cb += CHUNK) {
+        constexpr uint32_t UNITS = QUAD ? CHUNK / 4 : CHUNK; // edges (quads) of the concatenated rows a chunk takes
+        for (uint32_t cb = 0; cb < total; cb += UNITS) {
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
+            if (QUAD) {
+                // lane t takes BIN_EPT / 4 consecutive QUADS: one binary search, one step and ONE 16-byte load per quad
+                constexpr int QEPT = BIN_EPT / 4;
+                static_assert(!QUAD || BIN_EPT % 4 == 0, "whole quads per lane");
+                const uint32_t q0 = cb + threadIdx.x * QEPT;
+                uint32_t lo = 0;
+                if (q0 < total) {
+                    uint32_t hi = NT;
+#pragma unroll
+                    for (int it = 0; it < (NT == 256 ? 8 : NT == 512 ? 9 : 10); it++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= q0) lo = mid; else hi = mid;
+                    }
+                }
+                uint32_t sq[QEPT > 0 ? QEPT : 1];
+#pragma unroll
+                for (int j = 0; j < QEPT; j++) { // entries without edges: step over them
+                    const uint32_t qq = q0 + j;
+                    if (qq < total) while (s_pref[lo + 1] <= qq) lo++;
+                    sq[j] = lo;
+                }
+                uint4 x[QEPT > 0 ? QEPT : 1];
+#pragma unroll
+                for (int j = 0; j < QEPT; j++) { // straight-line: all loads in flight together
+                    const uint32_t qq = q0 + j;
+                    x[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    if (qq < total) x[j] = ((const uint4 *)colsrc)[s_ebeg[sq[j]] + (qq - s_pref[sq[j]])];
+                }
+#pragma unroll
+                for (int j = 0; j < QEPT; j++) {
+                    w[4 * j] = x[j].x; w[4 * j + 1] = x[j].y; w[4 * j + 2] = x[j].z; w[4 * j + 3] = x[j].w; // (padding words are 0xFFFFFFFF: no message)
+                    si[4 * j] = si[4 * j + 1] = si[4 * j + 2] = si[4 * j + 3] = sq[j];
+                }
+            } else {
             const uint32_t e0 = cb + threadIdx.x * BIN_EPT; // lane t takes 8 consecutive edges: ONE binary search for the source entry
             uint32_t lo = 0;
             if (e0 < total) {
@@ -851,6 +894,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                 const uint32_t e = e0 + k;
                 w[k] = 0xFFFFFFFFu;
                 if (e < total) w[k] = (uint32_t)colsrc[s_ebeg[si[k]] + (e - s_pref[si[k]])];
+            }
             }
             if (hubmode) {
 #pragma unroll
@@ -1844,6 +1888,17 @@ __global__ void __launch_bounds__(BLOCK) k_topk_frontier(Dev d, const uint8_t *a
         if (full) flush();
     }
     if (d.binned) flush();
+}
+
+// set_graph, wide layouts: dst := src with every row padded with -1 words to whole quads (Dev::col4); one thread per node
+// (a wave per 64 nodes: rows of neighbouring nodes are neighbours in both arrays).
+__global__ void __launch_bounds__(BLOCK) k_pad_quads(int32_t n, const int64_t *row_ptr, const int32_t *src, const uint64_t *rowinfo4, int32_t *dst) {
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < n; v += (int64_t)gridDim.x * BLOCK) {
+        const int64_t beg = row_ptr[v], deg = row_ptr[v + 1] - beg;
+        int32_t *out = dst + 4 * (int64_t)(rowinfo4[v] >> 24);
+        const int64_t padded = (deg + 3) & ~3ll;
+        for (int64_t i = 0; i < padded; i++) out[i] = i < deg ? src[beg + i] : -1;
+    }
 }
 
 // ppr := reserve for active slots (compute_ppr_with_reserve, query.h:243-253)
