@@ -75,6 +75,13 @@ def test_medium_wide_layout_bit_exact(engine, oracle, medium):
         assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
         assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
         assert _exit_condition_holds(res[i], g.deg, rmax)
+    # the bin kernel of this layout reads quad-padded copies of col / col_hub (Dev::col4, round 5); with option quads = 0 it
+    # reads single edges as the multi-pass layouts still do: same bits
+    engine.set_option("quads", 0)
+    rsv1, res1, _ = engine.push(srcs)
+    engine.set_option("quads", 1)
+    assert (rsv1 == rsv).all() and (res1 == res).all()
+    del rsv1, res1
     total, off, cnt = engine.index_sizes()
     t2, off2, cnt2 = oracle.index_sizes(g, rmax, omega)
     assert total == t2 and (off == off2).all() and (cnt == cnt2).all()
