@@ -172,7 +172,7 @@ def host_cpus():
             "threads_usable": usable, "machine_hardware_threads": os.cpu_count(), "model": model, "bind_order": order}
 
 
-def cpu_all_cores(g, sources, rmax, omega, args, index, threads, host):
+def cpu_all_cores(g, sources, rmax, omega, args, index, threads, host, one_thread_value=None):
     """the same oracle on T host threads, sources t, t + T, ... per thread -- pthreads inside the
     oracle (orc_query_many_pinned), every thread bound to one CPU of the process's affinity mask (physical cores first)
     and with its own buffers, allocated after binding, for the whole run.  Also a short scaling row (T = 1, 8, 64, ...)
@@ -187,10 +187,14 @@ def cpu_all_cores(g, sources, rmax, omega, args, index, threads, host):
                                    seed=0x464F5241, index=index, cpus=order[:max(1, min(t, len(order)))])
         rows.append({"threads": t, "queries": done, "seconds": dt, "value": done / dt})
     top = rows[-1]
-    one = rows[0]["value"] if rows[0]["threads"] == 1 else None
+    # the T = 1 rung of the ladder runs for a third of the budget over a handful of sources: noise.  The speed-up is quoted
+    # against the one-thread baseline of this same run (cpu_baseline: the full budget, the same source order)
+    one = one_thread_value if one_thread_value else (rows[0]["value"] if rows[0]["threads"] == 1 else None)
     return {"value": top["value"], "unit": "queries/s", "cores": min(host["physical_cores_allowed"], threads), "threads": threads, "kind": "port",
             "sample": f"{top['queries']} of the bench sources over {threads} pinned pthreads (sources tid mod T, private buffers), {top['seconds']:.1f} s",
-            "scaling": rows, "speedup_over_one_thread": (top["value"] / one) if one else None,
+            "scaling": rows, "scaling_note": "rungs below the top one run for a third of the budget each (`queries` = sources they finished): a trend, not a measurement",
+            "speedup_over_one_thread": (top["value"] / one) if one else None,
+            "speedup_reference": "cpu_baseline.value of this run (1 thread, full budget)" if one_thread_value else "first rung of `scaling`",
             "host": {k: v for k, v in host.items() if k != "bind_order"},
             "note": "every thread runs whole queries (a webstanford-sized query is 6.5 M scattered 8-byte read-modify-writes and 16 M "
                     "dependent walk steps over ~11 MB of private arrays); cores = physical cores the threads run on (one pinned thread per core up to the "
@@ -392,7 +396,42 @@ def run_workload(args, ctx, light=False):
         rounds_all = sum_over_ranks([float(np.sum(topk_out["rounds"])), float(len(mine))], world if use_dist else 1, dev)
         if rank != 0:
             return None
+        topk_roofline = None
+        push_ms = tm["push_expand_ms"] + tm["push_accum_ms"] + tm["push_tail_ms"] + tm.get("push_team_ms", 0.0) + tm["push_pop_ms"]
+        if not args.no_cpu and push_ms > 0:
+            # The pushes of the driver's rounds against 52 B per pop + 24 B per relaxation of the sequential FIFO
+            # (algo.h:1020-1093), counted by the oracle for the first sources with the round counts the GPU run took
+            # (the push does not depend on the walks, only the number of rounds does) and scaled to all sources by the
+            # GPU schedule's own counters of the same sources (one extra un-timed call).
+            import oracle_lib as O
+            g = O.Graph(n, m, row_ptr, col)
+            t1 = time.perf_counter()
+            fp = fe = nd = 0
+            for i, s_ in enumerate(mine[:32]):
+                a_, b_ = O.topk_push_counts(g, int(s_), args.topk, args.epsilon, int(topk_out["rounds"][i]))
+                fp += a_; fe += b_; nd += 1
+                if time.perf_counter() - t1 > min(args.fifo_sample_seconds, 12.0):
+                    break
+            t_fifo = time.perf_counter() - t1
+            eng.reset_timing()
+            _, _, r2 = eng.topk(mine[:nd], args.topk, epsilon=args.epsilon, with_idx=args.with_idx)
+            tms = eng.timing()
+            if tms["pops"] and tms["relax"] and (np.asarray(r2) == np.asarray(topk_out["rounds"][:nd])).all():
+                rp, re = fp / tms["pops"], fe / tms["relax"]
+                by = 52.0 * rp * tm["pops"] + 24.0 * re * tm["relax"]
+                topk_roofline = {
+                    "bound": "hbm", "achieved": by / (push_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": by / (push_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "the pushes of the top-k rounds: fora::k_pushq_bin + fora::k_accum<false> levels and fora::k_push_tail",
+                    "push_ms_per_step": push_ms / args.steps,
+                    "algorithmic_bytes": "52 B per pop + 24 B per edge relaxation",
+                    "algorithmic_counts": f"sequential FIFO top-k pushes (oracle, no walks) of the first {nd} sources with the GPU run's round "
+                                          f"counts, scaled to all sources by the GPU schedule's own counts (FIFO / GPU: pops {rp:.3f}, "
+                                          f"relaxations {re:.3f}; {t_fifo:.0f} s of one core)",
+                    "fifo_relaxations_per_query": re * tm["relax"] / max(1, len(mine) * args.steps),
+                    "gpu_relaxations_per_query": tm["relax"] / max(1, len(mine) * args.steps)}
         return {
+            "roofline": topk_roofline,
             "metric": "SSPPR top-k queries/sec at eps=0.5", "value": q_step_total * args.steps / dt,
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -452,7 +491,7 @@ def run_workload(args, ctx, light=False):
             host = host_cpus()
             threads = host["threads_usable"] if args.cpu_threads < 0 else min(args.cpu_threads, host["hardware_threads_allowed"])
             if threads > 1 and cpu["value"] * args.cpu_seconds >= 10:  # every thread runs at least one whole query: only when one fits the budget ten times over
-                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads, host)
+                out["cpu_baseline_all_cores"] = cpu_all_cores(g, mine, rmax, omega, args, index, threads, host, cpu["value"])
         elif per_query_guess <= 5.0:  # N > 1 or an extra configuration: only the algorithmic pop / relaxation counts of the FIFO oracle (push only, a few seconds)
             g = O.Graph(n, m, row_ptr, col)
             t1 = time.perf_counter()
@@ -521,7 +560,8 @@ def run_workload(args, ctx, light=False):
         # the unit of `achieved` / `traffic`: one launch of the dominant kernel WITH what belongs to it -- bucketed push: a level
         # launch of the bin kernel + its accumulate (the one k_push_tail of a batch counted as a launch of its own); team
         # push: the ONE k_push_team launch of a batch + the k_push_tail launch that finishes its slots (= the push of a batch)
-        launches = tm["push_team_launches"] if team else tm["push_expand_launches"] + tm["push_tail_launches"]
+        launches = (tm["push_team_launches"] + tm["push_expand_launches"]  # (bucketed launches beside team ones: a step fell back after a time-out)
+                    if team else tm["push_expand_launches"] + tm["push_tail_launches"])
         bucketed = tm["push_accum_launches"] > 0 or team
         # bucketed push: one level (and bin pass) is the kernel PAIR k_pushq_bin + k_accum<false> (same launch
         # count); the pop is split between them, so the pair carries the whole push: 52 B per pop + 24 B per edge
@@ -598,8 +638,29 @@ def run_workload(args, ctx, light=False):
             if sp is not None:
                 alt["in_run_sample"] = {"frac": (52.0 * sp + 24.0 * se) * q_timed / step_s / 1e9 / HBM_PEAK_GBS, "counts": sdesc}
         rf["frac_by_count_source"] = alt
+        if "in_run_sample" in alt:  # counts measured in THIS run are the quoted figure; the builder's ratio file is the cross-check
+            fr_ = alt["in_run_sample"]["frac"]
+            rf["frac"], rf["achieved"] = fr_, fr_ * HBM_PEAK_GBS
+            rf["algorithmic_bytes_per_launch"] = fr_ * HBM_PEAK_GBS * 1e9 * (rf["push_total"]["ms"] * 1e-3) / max(1, rf["launches"])
+            rf["algorithmic_counts"] = alt["in_run_sample"]["counts"]
+            rf["frac_quoted_from"] = "in_run_sample"
+            rf["push_total"]["achieved"] = fr_ * HBM_PEAK_GBS
     out.pop("_fifo_in_run", None); out.pop("_fifo_ratio_file", None)
     walk_bytes = (tm["walk_steps"] * 20.0 + tm["walks"] * 16.0) if not args.with_idx else tm["walks"] * 20.0
+    if not args.with_idx and tm["walk_ms"] > 0 and tm["walk_steps"]:
+        # The walk kernel is the dominant kernel of the headline step and has no HBM roofline (its working set is
+        # L2-resident): its rate of divergent gathers (one per step) against what the chip sustains for dependent
+        # gathers from a table of that size with nothing else to do (tools/gather_bench.hip), and its unit counters.
+        wb = {"kernel": "fora::k_walk_dg (online Philox walks over the degree-grouped copy: one gather per step)",
+              "gathers_per_s": tm["walk_steps"] / (tm["walk_ms"] * 1e-3), "steps": tm["walk_steps"] / max(1, args.steps), "walk_ms_per_step": tm["walk_ms"] / args.steps}
+        wpath = os.path.join(ROOT, "profiles", "walk_bound.json")
+        if os.path.exists(wpath) and args.graph == "webstanford":
+            ref = json.load(open(wpath))
+            wb["gather_bench_per_s"] = ref.get("gather_bench_per_s")
+            wb["frac_of_gather_bench"] = wb["gathers_per_s"] / ref["gather_bench_per_s"] if ref.get("gather_bench_per_s") else None
+            for k_ in ("ta_busy", "valu_busy", "floor_ms_all_gathers_hit_l1", "source"):
+                wb[k_] = ref.get(k_)
+        out["walk_bound"] = wb
     out["phases"] = {
         "push_pop_ms": tm["push_pop_ms"], "push_expand_ms": tm["push_expand_ms"], "push_accum_ms": tm["push_accum_ms"], "push_tail_ms": tm["push_tail_ms"],
         "push_team_ms": tm.get("push_team_ms", 0.0),
@@ -629,15 +690,20 @@ def summarize(d):
          "steps": d["steps"], "warmup": d["warmup"], "queries_per_step": d["config"].get("queries_per_step"),
          "batch": d["config"].get("batch"), "setup_s": d.get("setup_s") or
          {"graph": d["phases"]["graph_s"], "upload": d["phases"]["upload_s"], "index_build": d["phases"]["index_build_s"]}}
-    if "roofline" in d:
+    if d.get("roofline") and "launches" in d["roofline"]:
         r = d["roofline"]
         e["roofline"] = {k: r[k] for k in ("frac", "achieved", "peak", "unit", "kernel", "launches", "avg_launch_ms", "avg_ms_by_kernel",
                                            "algorithmic_bytes", "algorithmic_counts", "fifo_relaxations_per_query",
                                            "gpu_relaxations_per_query", "traffic", "traffic_upper_bound")}
         if "frac_by_count_source" in r:
             e["roofline"]["frac_by_count_source"] = r["frac_by_count_source"]
+    elif d.get("roofline"):
+        e["roofline"] = d["roofline"]
     ph = d.get("phases", {})
     e["phases_ms_per_step"] = {k: v / max(1, d["steps"]) for k, v in ph.items() if k.endswith("_ms")}
+    if d["config"].get("with_idx") and ph.get("walk_ms"):
+        e["walk_idx"] = {"kernel": "fora::k_walk_idx", "algorithmic_GBps": ph["walk_algorithmic_GBps"], "algorithmic_bytes": "20 B per indexed walk",
+                         "walks_per_s": ph["walks_per_s"], "frac_of_hbm_peak": ph["walk_algorithmic_GBps"] / HBM_PEAK_GBS}
     if "avg_rounds" in d["config"]:
         e["avg_rounds"] = d["config"]["avg_rounds"]
         e["k"] = d["config"]["k"]
@@ -677,7 +743,7 @@ def main():
         if not args.no_variants:
             # the plain R-MAT graph (about 43 % of the nodes have no out-edge; dangling sources finish at once,
             # dangling targets send their mass back to the source, algo.h:993-999): q/s over all and over the non-dangling sources
-            a = copy.copy(args); a.dangling = "rmat"; a.no_cpu = True; a.steps = 3; a.warmup = 1
+            a = copy.copy(args); a.dangling = "rmat"; a.steps = 3; a.warmup = 1  # (light: no CPU timing legs, but the FIFO push counts of its first sources)
             try:
                 d_all = run_workload(a, ctx, light=True)
                 n_nd = d_all["config"]["non_dangling_sources"]
@@ -697,7 +763,10 @@ def main():
                     "graph": d_all["config"]["workload"], "value_all_sources": d_all["value"],
                     "value_non_dangling_sources": len(nds) * a.steps / dt_nd, "unit": "queries/s",
                     "sources": int(a.queries), "non_dangling_sources": int(n_nd), "steps": a.steps,
-                    "roofline_frac_gpu_counts": d_all.get("roofline", {}).get("frac"),
+                    "roofline_frac": d_all.get("roofline", {}).get("frac"),  # on FIFO counts like the headline (round 5: GPU counts)
+                    "roofline_counts": d_all.get("roofline", {}).get("algorithmic_counts"),
+                    "roofline_kernel": d_all.get("roofline", {}).get("kernel"),
+                    "push_ms_by_kernel": d_all.get("roofline", {}).get("avg_ms_by_kernel"),
                     "phases_ms_per_step": {k: v / a.steps for k, v in d_all["phases"].items() if k.endswith("_ms")}}
             except Exception as e:  # never lose the headline line to an extra
                 out.setdefault("variants", {})["dangling_rmat"] = {"error": repr(e)[:300]}

@@ -57,9 +57,9 @@ struct Tunables {
                                  // CHANGES THE SCHEDULE (like rounds / round_div): results equal the twin run with the same value (orc_twin_set_defer).
                                  // ws, 1000 queries, defer 1: 13.5 % fewer relaxations and 6 % fewer walks, but 22-32 instead of 19 level launches and a longer tail: push 75 -> 99-114 ms
     int64_t defer_min = 0;       // with defer: only levels that pop at least this many nodes of the slot defer (orc_twin_set_defer_min)
-    int64_t team = -1;           // graphs of the narrow layout push with k_push_team (a slot's residue resident in the LDS of a team of workgroups, fora_team.h): 1 always, 0 never (the bucketed
-                                 // kernels), -1 (default): unless more than a fifth of the nodes are dangling.  Same bits either way.  Measured, push of 1000 queries: ws-sized graph 74.3 ms against
-                                 // 77.8 bucketed; R-MAT variant with 52 % dangling nodes (483 sources with out-edges, heavier pushes, 30 slots per team in a row) 47.3 against 41.3
+    int64_t team = -1;           // graphs of the narrow layout push with k_push_team (a slot's residue resident in the LDS of a team of workgroups, fora_team.h): 0 never (the bucketed
+                                 // kernels), 1 / -1 (default) always.  Same bits either way.  Measured, push of 1000 queries (round 6): ws-sized graph 45.7 + 4.9 ms against 77.8 bucketed; R-MAT
+                                 // variant with 52 % dangling nodes (483 sources with out-edges) 24.3 + 5.4 against 41.5 (round 4: 47.3 against 41.3, hence a gate on the dangling share until round 6)
     int64_t team_size = 0;       // members per team (a power of two up to 32); 0: the fewest whose LDS holds the graph; read by set_graph
     int64_t team_tail = -1;      // frontier size (of a slot) at which k_push_team hands the slot to k_push_tail; 0: never; -1: 4096
     int64_t team_xcd = 1;        // 1: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only)
@@ -67,6 +67,7 @@ struct Tunables {
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
     int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
+    int64_t team_abort_level = 0; // tests: every team abandons its launch (as after a time-out) when a slot reaches this level -- an abort in mid-flight: partial slabs, logs, message buffers, tagged words
     int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
     int64_t team_coop = 0;       // k_push_team launch: 0 (default) plain launch behind an occupancy check (occupancy x CUs >= grid, team_fits); 1: hipLaunchCooperativeKernel.  Measured on ROCm 7.2 / MI355X (round 5): the cooperative
                                  // launch costs ~9 ms per launch (push of 64 ws-sized queries 14.8 ms against 5.6: the runtime moves the launch to its cooperative queue and back) and a process with two contexts that used it crashed in the runtime's teardown -- opt-in only
@@ -82,7 +83,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_abort_level", &Tunables::team_abort_level, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -230,6 +231,8 @@ struct fora_ctx {
     fora_ctx *twin = nullptr;
     bool is_twin = false;
     uint32_t bk_scale = 1;        // bucket capacity multiplier, doubled after a bucket overflow (see with_bucket_retry)
+    uint32_t bk_scale_topk = 1;   // ... of the calls that plan with a divisor (bk_div > 1: the top-k driver on wide graphs).  Its own word: those calls start at 1 / 16 of a
+                                  // query's buckets and overflow far more often; a doubling there must not shrink the batches of later query / power-iteration calls
     uint64_t bucket_retries = 0;  // calls re-run with doubled buckets so far (fora_hip_get_option "bucket_retries")
     uint32_t bk_div = 1;          // bucket capacity divisor of the call in progress (top-k: TOPK_BK_DIV on wide graphs, plan_workspace)
     bool bucket_overflow = false; // the last device error was ERR_BUCKET_OVERFLOW
@@ -389,7 +392,7 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
             // a query's -- a slot is a fifth of the memory, a batch holds that many more of them, and every per-round launch
             // (k_push_tail: ONE workgroup per slot; the slab sweeps; the walk kernels) works on that many more slots at once.
             // A round that does overflow is run again with doubled buckets like any other (with_bucket_retry)
-            cap = std::min<uint64_t>(std::max<uint64_t>(cap * c->bk_scale / std::max<uint32_t>(1, c->bk_div), 64), 1u << 28);
+            cap = std::min<uint64_t>(std::max<uint64_t>(cap * (c->bk_div > 1 ? c->bk_scale_topk : c->bk_scale) / std::max<uint32_t>(1, c->bk_div), 64), 1u << 28);
             p.bk_cap = (uint32_t)((cap + 15) & ~15ull);
         }
         p.segq_cap = n; // frontier positions
@@ -444,7 +447,7 @@ int ensure_row_split(fora_ctx *c, int nbins, int pbins) {
 // col that names every target as (owner, local id) and the exact bucket capacities.  Built on first use and whenever
 // the `team` / `team_size` options ask for another shape.
 static bool want_team(const fora_ctx *c) {
-    const bool on = c->opt_.team == 1 || (c->opt_.team < 0 && c->dangling_frac <= 0.2);
+    const bool on = c->opt_.team != 0; // (round 6: also for graphs with many dangling nodes -- 29.7 against 41.7 ms on the R-MAT ws variant, profiles/r06_dangling_team.txt)
     return on && want_binned(c) && !want_wide(c) && c->nnz > 0 && c->nnz < (1ll << 32); // (rowl / colt / off index edges with 32 bits)
 }
 int ensure_team(fora_ctx *c) {
@@ -637,11 +640,7 @@ int ensure_workspace(fora_ctx *c, int want_slots, double omega_hint) {
             while (c->team_rlog_cap > 1024 && per_team_bytes(c->team_rlog_cap) > fr / 4) c->team_rlog_cap /= 2;
             const uint64_t per_team = per_team_bytes(c->team_rlog_cap);
             nteams = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nteams, (uint64_t)(fr / 2) / std::max<uint64_t>(1, per_team)));
-#if defined(FORA_PROBE_STORE) || defined(FORA_PROBE_STORE2)
-            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64 + (size_t)(80000000) * 4 + (1 << 20)));
-#else
-            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64));
-#endif
+            HIPCHK(c, hipMalloc(&c->d_team_msg, (size_t)nteams * 2 * c->team_cap * 4 + 64 + diag::TEAM_MSG_PROBE_WORDS * 4)); // (probe words: 0 in the product build)
             HIPCHK(c, hipMalloc(&c->d_team_inct, (size_t)nteams * 2 * T * (c->team_R + 64 + c->team_H) * 8));
             HIPCHK(c, hipMalloc(&c->d_team_rsvl, (size_t)nteams * T * c->team_R * 8));
             HIPCHK(c, hipMemset(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8)); // every slot leaves it zero again
@@ -1000,6 +999,7 @@ int run_push_team(fora_ctx *c, const Dev &d) {
     const uint32_t grid = nteams * T;
     a.xcd = (c->opt_.team_xcd >= 1 && grid % 8 == 0 && (grid / 8) % T == 0) ? (uint32_t)c->opt_.team_xcd : 0u;
     a.stamps = c->d_stamps;
+    a.abort_level = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_abort_level, 0), 1 << 20);
     a.timeout_ticks = (uint64_t)std::min<int64_t>(std::max<int64_t>(c->opt_.team_timeout_ms, 0), 60000) * 100000ull; // (100 MHz wall clock)
     const size_t lds = ((size_t)a.R + 1 + a.H) * 8;
     if (c->team_dirty) { HIPCHK(c, hipMemsetAsync(c->d_team_rsvl, 0, (size_t)nteams * T * c->team_R * 8, c->stream)); c->team_dirty = false; }
@@ -1313,7 +1313,7 @@ int sync_twin(fora_ctx *c) {
     w->rmax = c->rmax; w->omega = c->omega; w->opt = c->opt; w->seed = c->seed;
     w->d_rw_idx = c->d_rw_idx; w->d_idx_off = c->d_idx_off; w->d_idx_cnt = c->d_idx_cnt;
     w->idx_len = c->idx_len; w->have_index = c->have_index;
-    w->bk_scale = c->bk_scale;
+    w->bk_scale = c->bk_scale; w->bk_scale_topk = c->bk_scale_topk;
     w->d_stamps = c->d_stamps;
     w->opt_ = c->opt_;
     w->balanced = c->balanced; w->bal_start = c->bal_start; w->c_pop = c->c_pop; w->c_edge = c->c_edge; w->t_walk = c->t_walk; w->t_idx = c->t_idx;
@@ -1428,7 +1428,7 @@ int query_common(fora_ctx *c, const int32_t *sources, int nq, int with_idx, int 
 // context's kernels held CUs) -- the next calls push with the bucketed kernels.
 constexpr int TEAM_SUSPEND_CALLS = 8;
 template <class F> int with_bucket_retry(fora_ctx *c, F call) {
-    const uint32_t scale0 = c ? c->bk_scale : 1;
+    const uint32_t scale0 = c ? c->bk_scale : 1, scale0t = c ? c->bk_scale_topk : 1;
     bool team_retried = false;
     auto forget_attempt = [&](const fora_timing &t0) { // the failed attempt must leave no trace in the timings: drop its event pairs and counters
         (void)hipSetDevice(c->device);
@@ -1442,17 +1442,23 @@ template <class F> int with_bucket_retry(fora_ctx *c, F call) {
             c->twin->pending_nq = 0;
         }
     };
+    auto set_scales = [&](uint32_t s, uint32_t st) {
+        c->bk_scale = s; c->bk_scale_topk = st;
+        if (c->twin) { c->twin->bk_scale = s; c->twin->bk_scale_topk = st; }
+    };
+    auto drop_enlarged_plan = [&]() { // the enlarged plan did not help: do not keep it
+        if (c->bk_scale == scale0 && c->bk_scale_topk == scale0t) return;
+        set_scales(scale0, scale0t);
+        (void)hipSetDevice(c->device);
+        free_workspace(c);
+        if (c->twin) free_workspace(c->twin);
+    };
     for (;;) {
         const fora_timing t0 = c ? c->timing : fora_timing{};
         const int rc = call();
         if (c && rc == FORA_OK && c->team_suspend > 0 && !team_retried) c->team_suspend--; // (a retried call has just started the count)
         if (!c || rc != FORA_E_OVERFLOW) {
-            if (c && rc != FORA_OK && c->bk_scale != scale0) { // the enlarged plan did not help: do not keep it
-                c->bk_scale = scale0;
-                (void)hipSetDevice(c->device);
-                free_workspace(c);
-                if (c->twin) { c->twin->bk_scale = scale0; free_workspace(c->twin); }
-            }
+            if (c && rc != FORA_OK) drop_enlarged_plan();
             return rc;
         }
         if (c->team_timeout_seen && !team_retried) {
@@ -1464,23 +1470,18 @@ template <class F> int with_bucket_retry(fora_ctx *c, F call) {
             continue;
         }
         const bool bucket = c->bucket_overflow || (c->twin && c->twin->bucket_overflow);
-        if (!bucket || c->bk_scale >= (1u << 16)) {
-            if (c->bk_scale != scale0) {
-                c->bk_scale = scale0;
-                (void)hipSetDevice(c->device);
-                free_workspace(c);
-                if (c->twin) { c->twin->bk_scale = scale0; free_workspace(c->twin); }
-            }
+        // the multiplier of the regime the call planned with (fora_ctx::bk_div is set by the call itself)
+        const bool topk_regime = c->bk_div > 1;
+        const uint32_t cur = topk_regime ? c->bk_scale_topk : c->bk_scale;
+        if (!bucket || cur >= (1u << 16)) {
+            drop_enlarged_plan();
             return rc;
         }
-        c->bk_scale *= 2;
+        set_scales(topk_regime ? c->bk_scale : c->bk_scale * 2, topk_regime ? c->bk_scale_topk * 2 : c->bk_scale_topk);
         c->bucket_retries++;
         c->bucket_overflow = false;
         forget_attempt(t0);
-        if (c->twin) {
-            c->twin->bucket_overflow = false;
-            c->twin->bk_scale = c->bk_scale;
-        }
+        if (c->twin) c->twin->bucket_overflow = false;
         free_workspace(c);
         if (c->twin) free_workspace(c->twin);
     }
@@ -1628,14 +1629,22 @@ static int build_quad_copies(fora_ctx *c) {
         q += (dg + 3) / 4;
     }
     if (q >= (1ull << 40)) return FORA_OK;
-    HIPCHK(c, hipMalloc(&c->d_rowinfo4, n * 8));
+    // The copies are an optimisation (make_dev falls back to single-edge reads without them): they must never make
+    // set_graph fail.  Not built when they would take more than a quarter of the free memory (the slots need it more);
+    // an allocation that fails all the same leaves "no quads", not an error.
+    const uint64_t qbytes = std::max<uint64_t>(1, q) * 16, need = n * 8 + qbytes * (c->d_col_hub ? 2 : 1);
+    size_t fr = 0, tot = 0;
+    HIPCHK(c, hipMemGetInfo(&fr, &tot));
+    if (need > fr / 4) return FORA_OK;
+    auto give_up = [&]() { (void)hipGetLastError(); dfree(c->d_col4); dfree(c->d_col_hub4); dfree(c->d_rowinfo4); c->quads = 0; return FORA_OK; };
+    if (hipMalloc(&c->d_rowinfo4, n * 8) != hipSuccess) return give_up();
     HIPCHK(c, hipMemcpy(c->d_rowinfo4, ri4.data(), n * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMalloc(&c->d_col4, std::max<uint64_t>(1, q) * 16));
+    if (hipMalloc(&c->d_col4, qbytes) != hipSuccess) return give_up();
     const unsigned grid = (unsigned)std::min<size_t>((n + BLOCK - 1) / BLOCK, 1u << 20);
     hipLaunchKernelGGL(k_pad_quads, dim3(grid), dim3(BLOCK), 0, c->stream, c->n, (const int64_t *)c->d_row_ptr, (const int32_t *)c->d_col,
                        (const uint64_t *)c->d_rowinfo4, c->d_col4);
     if (c->d_col_hub) {
-        HIPCHK(c, hipMalloc(&c->d_col_hub4, std::max<uint64_t>(1, q) * 16));
+        if (hipMalloc(&c->d_col_hub4, qbytes) != hipSuccess) return give_up();
         hipLaunchKernelGGL(k_pad_quads, dim3(grid), dim3(BLOCK), 0, c->stream, c->n, (const int64_t *)c->d_row_ptr, (const int32_t *)c->d_col_hub,
                            (const uint64_t *)c->d_rowinfo4, c->d_col_hub4);
     }
@@ -1765,7 +1774,7 @@ int fora_hip_set_graph(fora_ctx *c, int32_t n, int64_t m_attr, const int64_t *ro
     if (c->twin) free_workspace(c->twin);
     free_index(c);
     free_graph(c);
-    c->bk_scale = 1;
+    c->bk_scale = 1; c->bk_scale_topk = 1;
     std::vector<uint64_t> rowinfo((size_t)n);
     std::vector<uint32_t> deg((size_t)n);
     int64_t n_dangling = 0;
@@ -1882,9 +1891,12 @@ int fora_hip_set_option(fora_ctx *c, const char *name, int64_t value) {
 }
 
 int fora_hip_get_option(fora_ctx *c, const char *name, int64_t *value) {
-    if (!c || !name || !value) return FORA_E_ARG;
-    // read-only state of the engine beside the knobs
+    if (!name || !value) return FORA_E_ARG;
+    // properties of the BUILD: answered without a context (and so without a GPU)
     if (!strcmp(name, "test_paths")) { *value = TEST_PATHS ? 1 : 0; return FORA_OK; } // 1: libfora_hip_test.so (schedule experiments compiled in)
+    if (!strcmp(name, "diag_build")) { *value = FORA_DIAG_BUILD; return FORA_OK; }    // 1: a probe / stamp / fake build (fora_diag.h) -- never the shipped library
+    if (!c) return FORA_E_ARG;
+    // read-only state of the engine beside the knobs
     if (!strcmp(name, "bucket_retries")) { *value = (int64_t)c->bucket_retries; return FORA_OK; } // re-runs with doubled message buckets
     if (!strcmp(name, "team_fallbacks")) { *value = (int64_t)c->team_fallbacks; return FORA_OK; } // calls re-run with the bucketed push after a team time-out
     if (!strcmp(name, "team_suspended")) { *value = c->team_suspend; return FORA_OK; }             // calls left that do not try the team push

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "fora_diag.h"
 
 namespace fora {
 
@@ -305,15 +306,7 @@ struct Dev {
 
 // ------------------------------------------------------------------ helpers
 // Diagnostic build: thread 0 of a workgroup adds the shader-clock cycles since the previous stamp to d.stamps[slot].
-#ifdef FORA_STAMPS
-#define STAMP_DECL long long st_t_ = clock64(); unsigned long long st_a_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)st_a_;
-#define STAMP(slot) do { const long long n_ = clock64(); st_a_[(slot) & 7] += (unsigned long long)(n_ - st_t_); st_t_ = n_; } while (0)
-#define STAMP_FLUSH(base) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) if (st_a_[i_]) atomicAdd(&d.stamps[(base) + i_], st_a_[i_]); } while (0)
-#else
-#define STAMP_DECL
-#define STAMP(slot) do {} while (0)
-#define STAMP_FLUSH(base) do {} while (0)
-#endif
+// (phase stamps and probes: fora_diag.h -- empty in the product build)
 __device__ __forceinline__ uint64_t mulshift62(uint64_t r, uint64_t a) {
     return (__umul64hi(r, a) << 2) | ((r * a) >> 62);
 }
@@ -774,6 +767,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     // s_fill: messages this workgroup has put into its sub-bucket of the bin so far
     __shared__ uint32_t s_cnt[NB], s_lofs[NB + 1];
     __shared__ uint32_t s_fill[NB];
+    BIN_RANK_PROBE_DECL(NB)
     // stage: ONE word per message and its bin.  narrow: (local target << SEG_BITS) | frontier position;
     // wide: local target (13 bits) | source entry inside the tile (SRC_BITS)
     __shared__ uint32_t s_msg[CHUNK];
@@ -840,7 +834,11 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         for (uint32_t cb = 0; cb < total; cb += UNITS) {
             uint32_t w[BIN_EPT], rank[BIN_EPT], si[BIN_EPT];
             if (QUAD) {
-                // lane t takes BIN_EPT / 4 consecutive QUADS: one binary search, one step and ONE 16-byte load per quad
+                // lane t takes BIN_EPT / 4 consecutive QUADS: one binary search, one step and ONE 16-byte load per quad.
+                // (Round 6, measured and dropped: the loads of chunk c + 1 issued as soon as chunk c's quads are unpacked, so that they
+                // fly while chunk c is ranked, staged and written out -- LJ-sized 304.7 / 313.0 against 310.9 / 311.1 ms, Twitter-2010-sized
+                // 594 / 587 against 586 / 587, 17 VGPR spills in <2560>: the other waves already cover that latency; what one more load per
+                // quad costs (+ 25 % / + 17 %, profiles/r06_wide_probes.txt) is memory-system throughput for short random rows.)
                 constexpr int QEPT = BIN_EPT / 4;
                 static_assert(!QUAD || BIN_EPT % 4 == 0, "whole quads per lane");
                 const uint32_t q0 = cb + threadIdx.x * QEPT;
@@ -860,15 +858,21 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     if (qq < total) while (s_pref[lo + 1] <= qq) lo++;
                     sq[j] = lo;
                 }
-                uint4 x[QEPT > 0 ? QEPT : 1];
+                uint4 x[QEPT > 0 ? QEPT : 1], xp[QEPT > 0 ? QEPT : 1];
 #pragma unroll
                 for (int j = 0; j < QEPT; j++) { // straight-line: all loads in flight together
                     const uint32_t qq = q0 + j;
                     x[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                    if (qq < total) x[j] = ((const uint4 *)colsrc)[s_ebeg[sq[j]] + (qq - s_pref[sq[j]])];
+                    xp[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (qq < total) {
+                        const int64_t at = s_ebeg[sq[j]] + (qq - s_pref[sq[j]]);
+                        x[j] = ((const uint4 *)colsrc)[at];
+                        xp[j] = diag::bin_load_probe(colsrc, d.col4, d.col_hub4, d.col, at);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < QEPT; j++) {
+                    diag::bin_load_keep(xp[j]);
                     w[4 * j] = x[j].x; w[4 * j + 1] = x[j].y; w[4 * j + 2] = x[j].z; w[4 * j + 3] = x[j].w; // (padding words are 0xFFFFFFFF: no message)
                     si[4 * j] = si[4 * j + 1] = si[4 * j + 2] = si[4 * j + 3] = sq[j];
                 }
@@ -908,7 +912,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             for (int k = 0; k < BIN_EPT; k++) {
                 if (w[k] != 0xFFFFFFFFu && (w[k] >> BS) - bin_lo >= bin_cnt) w[k] = 0xFFFFFFFFu; // another pass's bins
                 if (w[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&s_cnt[(w[k] >> BS) - bin_lo], 1u); // rank inside (chunk, bin)
+                if (w[k] != 0xFFFFFFFFu) BIN_RANK_PROBE((w[k] >> BS) - bin_lo);
             }
+            diag::bin_sync_probe();
             __syncthreads();
             STAMP(1);
             uint32_t staged; // messages of this chunk that belong to the pass's bins
@@ -947,7 +953,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     const uint32_t b = (w[k] >> BS) - bin_lo;
                     const uint32_t sp = s_lofs[b] + rank[k];
                     const uint32_t own = si[k];
-                    s_msg[sp] = WIDE ? (w[k] & (BSZ - 1)) | (own << BS) : ((w[k] & (BSZ - 1)) << SEG_BITS) | tile_pos<GRAN>(own, tile, seg_len);
+                    const uint32_t sw = WIDE ? (w[k] & (BSZ - 1)) | (own << BS) : ((w[k] & (BSZ - 1)) << SEG_BITS) | tile_pos<GRAN>(own, tile, seg_len);
+                    s_msg[sp] = sw;
+                    diag::bin_lds_write_probe(s_msg, sp, sw);
                     s_bin[sp] = b;
                 }
             }
@@ -955,6 +963,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
             STAMP(3);
             for (uint32_t m = threadIdx.x; m < staged; m += NT) { // consecutive lanes -> consecutive bucket slots
                 const uint32_t e = s_msg[m];
+                diag::bin_lds_read_probe(s_msg, m);
                 const uint32_t b = s_bin[m];
                 uint32_t sidx = 0, local;
                 if (WIDE) { sidx = e >> BS; local = e & (BSZ - 1); }
@@ -967,7 +976,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
                     if (WIDE) {
                         const uint64_t inc = s_inc[sidx];
                         parked = inc >= WIDE_MAXV; // does not fit the packed word: null word here, the increment goes to the list
-                        d.bk_inc[at] = parked ? 0ull : (uint64_t)local | (inc << BS);
+                        const uint64_t mword = parked ? 0ull : (uint64_t)local | (inc << BS);
+                        d.bk_inc[at] = mword;
+                        diag::bin_store_probe(&d.bk_inc[at], mword);
                     } else d.bk_w[at] = e;
                 }
                 if (parked) { // park the increment in the slot's overflow list, folded in by k_accum
@@ -1055,6 +1066,12 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
     __shared__ uint32_t s_scan[TAIL_THREADS / 64];
     __shared__ uint32_t s_next, s_count, s_ndue, s_nwait, s_real;
     __shared__ unsigned long long s_dang;
+    // Round 6: a small level is a chain of dependent round trips (profiles/r06_tail.txt: nine of them per level, one workgroup per
+    // slot, nothing to overlap them with).  A level of at most TAIL_THREADS nodes now (a) takes its list from LDS (s_front: the
+    // crossing nodes of the level before, also stored to the slot's global list as before), (b) pops in the tile prologue -- residue
+    // exchange, row word and degree of a node in ONE round trip, the increment stays in LDS instead of going through inc_tab --,
+    // (c) knows its size from LDS, and (d) the hubs' node ids / degrees sit in registers for the launch: four round trips per level.
+    __shared__ uint32_t s_front[2][TAIL_THREADS];
     constexpr uint32_t HOLE = 0x80000000u; // list entry of a node that crossed but waits a level (bounded deferral): skipped by the pops
     // The chip takes 23 G returning atomics per second whatever their addresses (profiles/r01_atomics_microbench.txt), and
     // this kernel issues little else: with a hub copy of the graph (Dev::col_hub) the increments for the hubs -- 45 % of all
@@ -1068,6 +1085,15 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
     const uint32_t src = (uint32_t)d.src[q];
     const int dk = (!TEST_PATHS || max_levels > 0) ? 0 : d.defer_k; // capped runs (power iteration) keep plain levels
     if (hubmode) for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS) s_hubt[h] = 0;
+    constexpr int HPT = 4; // hubs per thread whose node id and threshold-degree ride in registers (hubs beyond HPT * TAIL_THREADS: loaded per level)
+    uint32_t hub_w[HPT], hub_dg[HPT];
+#pragma unroll
+    for (int k = 0; k < HPT; k++) {
+        const uint32_t h = k * TAIL_THREADS + tid;
+        hub_w[k] = hubmode && h < d.hubs ? d.hub_node[h] : 0u;
+        hub_dg[k] = hubmode && h < d.hubs ? d.deg[hub_w[k]] : 0u;
+    }
+    bool list_in_lds = false; // the level's list is complete in s_front[L & 1] (wave-uniform, same in every thread)
     uint64_t acc_res = 0, acc_pops = 0, acc_relax = 0;
     int L = L0;
     uint32_t levels_run = 0;
@@ -1098,7 +1124,7 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
         const int par = L & 1;
         uint64_t *incs = d.inc_tab[par] + (uint64_t)q * d.segq_cap;
         if (tid == 0) {
-            s_count = __atomic_load_n(&d.fl_count[par][q * CSTRIDE], __ATOMIC_RELAXED);
+            if (done == 0) s_count = __atomic_load_n(&d.fl_count[par][q * CSTRIDE], __ATOMIC_RELAXED); // (later levels: set at the end of the level before)
             s_next = 0;
             s_nwait = 0;
             s_dang = 0;
@@ -1112,7 +1138,9 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
         // ---- all pops of the level (algo.h:983-1002).  The entries of level L0 carry the residue already taken from
         // their nodes (see k_accum); later levels are collected by this kernel and take it here.
         if (real) levels_run++;
-        for (uint32_t i = tid; i < count; i += TAIL_THREADS) {
+        const bool fused = count <= (uint32_t)TAIL_THREADS && !dk; // one tile: the pops happen in its prologue (no holes without deferral)
+        uint32_t *nxt = s_front[par ^ 1];
+        for (uint32_t i = tid; !fused && i < count; i += TAIL_THREADS) {
             const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
             if (v & HOLE) continue;
             const uint64_t a = slab + v;
@@ -1134,7 +1162,26 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
         for (uint32_t tbase = 0; tbase < count; tbase += TAIL_THREADS) {
             const uint32_t i = tbase + tid;
             uint32_t cnt = 0;
-            if (i < count) {
+            if (fused) {
+                if (i < count) { // the pop (algo.h:983-1002) and the row of the node in one round trip
+                    const uint32_t v = list_in_lds ? s_front[par][i] : __atomic_load_n(&in[i], __ATOMIC_RELAXED);
+                    const uint64_t a = slab + v;
+                    const uint64_t r = done ? atomicExch((unsigned long long *)&d.residue[a], 0ull)      // algo.h:984-985
+                                            : __atomic_load_n(&incs[i], __ATOMIC_RELAXED);
+                    int64_t beg; uint64_t deg;
+                    node_row(d, v, beg, deg);
+                    uint64_t res_add, dang;
+                    const uint64_t inc = pop_value(d.afix, r, (uint32_t)deg, res_add, dang);             // algo.h:986-1002
+                    if (dang) atomicAdd(&s_dang, (unsigned long long)dang);                               // algo.h:993-994
+                    atomicAdd((unsigned long long *)&d.ppr[a], (unsigned long long)res_add);              // algo.h:986-989
+                    acc_res += res_add;
+                    acc_pops++;
+                    acc_relax += deg;
+                    s_ebeg[tid] = beg;
+                    s_inc[tid] = inc;
+                    cnt = inc ? (uint32_t)deg : 0u;
+                }
+            } else if (i < count) {
                 const uint32_t v = __atomic_load_n(&in[i], __ATOMIC_RELAXED);
                 if (!(v & HOLE)) {
                     int64_t beg; uint64_t deg;
@@ -1201,6 +1248,7 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
                         if (old[k] < thr && old[k] + inc[k] >= thr) { // crossed in this level: next frontier (algo.h:1012-1015)
                             const uint32_t pos = atomicAdd(&s_next, 1u);
                             if (pos < (uint32_t)d.n) out[pos] = w[k]; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                            if (pos < (uint32_t)TAIL_THREADS) nxt[pos] = w[k];
                         }
                     }
                 }
@@ -1208,16 +1256,23 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
             __syncthreads();
         }
         if (hubmode) { // the hubs' sums of the level (every add to s_hubt is behind the tile loop's last barrier)
-            for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS) {
+            uint32_t k = 0;
+            for (uint32_t h = tid; h < d.hubs; h += TAIL_THREADS, k++) {
                 const uint64_t hv = s_hubt[h];
                 if (!hv) continue;
                 s_hubt[h] = 0;
-                const uint32_t w = d.hub_node[h];
+                uint32_t w, wdg;
+                if (k < (uint32_t)HPT) { // (registers; the compiler unrolls the select over the HPT pairs)
+                    w = hub_w[0]; wdg = hub_dg[0];
+#pragma unroll
+                    for (int kk = 1; kk < HPT; kk++) if (k == (uint32_t)kk) { w = hub_w[kk]; wdg = hub_dg[kk]; }
+                } else { w = d.hub_node[h]; wdg = d.deg[w]; }
                 const uint64_t old = atomicAdd((unsigned long long *)&d.residue[slab + w], (unsigned long long)hv);
-                const uint64_t thr = node_thr(d.t1, d.deg[w]);
+                const uint64_t thr = node_thr(d.t1, wdg);
                 if (old < thr && old + hv >= thr) { // (algo.h:1012-1015: crossed in this level)
                     const uint32_t pos = atomicAdd(&s_next, 1u);
                     if (pos < (uint32_t)d.n) out[pos] = w; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                    if (pos < (uint32_t)TAIL_THREADS) nxt[pos] = w;
                 }
             }
         }
@@ -1229,10 +1284,12 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
             if (old < thr && old + dm >= thr) {
                 const uint32_t pos = atomicAdd(&s_next, 1u);
                 if (pos < (uint32_t)d.n) out[pos] = src; else atomicOr(d.err, ERR_WL_OVERFLOW);
+                if (pos < (uint32_t)TAIL_THREADS) nxt[pos] = src;
             }
         }
         __syncthreads();
         uint32_t crossed = min(s_next, (uint32_t)d.n);
+        list_in_lds = !dk && crossed <= (uint32_t)TAIL_THREADS; // (every entry of the next list went to s_front too)
         if (dk) {
             const int dkl = real >= d.defer_min ? dk : 0; // this level defers only if it popped enough nodes
             // bounded deferral (see Dev::dbm): every add of the level has landed; a node that only just crossed becomes a
@@ -1255,7 +1312,8 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
         }
         if (tid == 0) {
             const uint32_t nwait = dk ? s_nwait : 0u;
-            d.fl_count[par ^ 1][q * CSTRIDE] = min(crossed + (dk ? ndue : 0u), (uint32_t)d.n);
+            s_count = min(crossed + (dk ? ndue : 0u), (uint32_t)d.n); // the next level's list size (also in the slot's global word: a capped run ends here)
+            d.fl_count[par ^ 1][q * CSTRIDE] = s_count;
             d.fl_count[par][q * CSTRIDE] = 0;
             s_real = crossed - nwait + (dk ? ndue : 0u);
             s_ndue = nwait;
@@ -1468,7 +1526,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
         const uint64_t at0 = bk0 + (uint64_t)x * d.bk_cap;
         for (uint32_t i0 = 0; i0 < n_x; i0 += 64 * ACC_UNROLL) { // (two sub-buckets per trip, 8 loads in flight: no gain measured)
             uint32_t mw[ACC_UNROLL];
-            uint64_t mi[ACC_UNROLL];
+            uint64_t mi[ACC_UNROLL], mp[ACC_UNROLL];
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
@@ -1478,6 +1536,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
             for (int k = 0; k < ACC_UNROLL; k++) {
                 const uint32_t i = i0 + k * 64 + lane;
                 mi[k] = gather ? itab[mw[k] & ((1u << SEG_BITS) - 1)] : NT_LOAD(&d.bk_inc[at0 + (i < n_x ? i : 0)]);
+                mp[k] = packed ? diag::acc_load_probe(&d.bk_inc[at0 + (i < n_x ? i : 0)]) : 0ull;
             }
 #pragma unroll
             for (int k = 0; k < ACC_UNROLL; k++) {
@@ -1486,6 +1545,8 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
                 uint64_t inc = mi[k];
                 if (packed) { local = (uint32_t)inc; inc >>= pshift; }
                 if (i < n_x && inc) atomicAdd((unsigned long long *)&acc[local & (BSZ - 1)], (unsigned long long)inc);
+                if (i < n_x && inc) diag::acc_atom_probe(&acc[local & (BSZ - 1)]);
+                diag::acc_load_keep(mp[k]);
             }
         }
     }
@@ -1535,6 +1596,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
                 }
             }
         }
+        uint64_t swp = 0; // (diag::acc_sweep_probe: always 0 in the product build)
 #pragma unroll
         for (int k = 0; k < SWEEP; k++) {
             old[k] = 0; dg[k] = 0;
@@ -1542,8 +1604,10 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
                 const uint32_t node = node0 + k * AT + threadIdx.x;
                 old[k] = target[slab + node];
                 if (!TO_PPR) dg[k] = d.deg[node];
+                if (!TO_PPR) swp += diag::acc_sweep_probe(&target[slab + node], &d.deg[node]);
             }
         }
+        diag::acc_sweep_keep(swp);
         const bool pop = !TO_PPR && d.pop_next;
         uint32_t defmask = 0; // bit k: the node crossed but waits a level
 #pragma unroll
@@ -2719,7 +2783,7 @@ __device__ __forceinline__ uint32_t dg_colp_at(const WalkDG &g, uint32_t e) {
 template <bool NZH, bool BITS32, bool XL>
 __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu(FORA_DG_WPE, 8))) k_walk_dg(Dev d, uint32_t round) {
     constexpr int NW = DG_THREADS / 64;
-    extern __shared__ uint64_t dg_lds64[]; // XL: hub accumulators [H] (u64) | first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
+    extern __shared__ __attribute__((aligned(16))) uint64_t dg_lds64[]; // (16-byte aligned: the records below are read as uint4) // XL: hub accumulators [H] (u64) | first[nrec] | deg[nrec] | base[nrec] | T[nblk] (bytes)
     // Walk items are staged per WAVE, WT at a time: a walk that has started lives in its lane's registers, so the wave
     // loads its next WT items as soon as the walks of the current ones are handed out -- lanes never wait for the longest
     // walk of a tile to end, and the loop has no workgroup barrier.  (First form: 256 items per workgroup between two
@@ -2865,24 +2929,14 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                 done = (int32_t)cur;
                 active = false;
             } else {
-#if defined(FORA_DG_FAKE_STEP0) // diagnostic only (wrong results): what the kernel would take if the first step of every walk hit L1
-                cur = t == 0 ? move(cur & 1023u, startp, rw[1]) : move(cur, startp, rw[1]);
-#elif defined(FORA_DG_FAKE_ALL) // diagnostic only: every step's gather from a 4-KB window (the kernel's floor without misses)
-                cur = move(cur & 1023u, startp, rw[1]);
-#else
-                cur = move(cur, startp, rw[1]);
-#endif
+                cur = move(diag::dg_from(cur, t), startp, rw[1]); // (diag::dg_from: the identity in the product build)
                 steps++;
                 if (rw[2] < d.alpha32) {
                     t++;
                     done = (int32_t)cur;
                     active = false;
                 } else {
-#if defined(FORA_DG_FAKE_ALL)
-                    cur = move(cur & 1023u, startp, rw[3]);
-#else
-                    cur = move(cur, startp, rw[3]);
-#endif
+                    cur = move(diag::dg_from(cur, 1u), startp, rw[3]);
                     t += 2;
                     steps++;
                 }

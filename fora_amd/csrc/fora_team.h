@@ -117,6 +117,7 @@ struct TeamDev {
     uint32_t xcd;                  // != 0: the members of a team share blockIdx % 8 (one XCD under round-robin placement: speed only; the kernel checks where they really are); 2: the same, but always with the fences (tests)
     unsigned long long *stamps;    // diagnostic builds (-DFORA_STAMPS): cycles per phase of thread 0, summed over workgroups, [0..7]
     uint64_t timeout_ticks;        // wall_clock64 ticks (100 MHz) a member waits for its team before it gives up
+    uint32_t abort_level;          // tests (option team_abort_level): != 0: every member abandons the launch when its slot reaches this level, as after a time-out
 };
 
 // The kernel never keeps its argument struct in registers.  By value, the ~45 fields were loaded at the kernel's entry
@@ -169,19 +170,7 @@ __device__ __forceinline__ bool team_wait(DONE done) {
     }
 }
 
-#ifdef FORA_STAMPS
-#define TSTAMP_DECL long long ts_t_ = clock64(); unsigned long long ts_a_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; bool ts_on_ = true; (void)ts_on_;
-#ifdef FORA_STAMPS_SMALL // only the levels whose predecessor popped at most FORA_STAMPS_SMALL nodes of the slot: where the fixed cost of a level goes
-#define TSTAMP(k) do { const long long n_ = clock64(); if (ts_on_) ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
-#else
-#define TSTAMP(k) do { const long long n_ = clock64(); ts_a_[k] += (unsigned long long)(n_ - ts_t_); ts_t_ = n_; } while (0)
-#endif
-#define TSTAMP_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 10; i_++) if (ts_a_[i_]) atomicAdd(&team_args()->stamps[i_], ts_a_[i_]); } while (0)
-#else
-#define TSTAMP_DECL
-#define TSTAMP(k) do {} while (0)
-#define TSTAMP_FLUSH() do {} while (0)
-#endif
+// (TSTAMP* phase stamps and the marginal-cost probes: fora_diag.h -- empty in the product build)
 
 #ifndef FORA_TEAM_HEAVY
 #define FORA_TEAM_HEAVY 1024
@@ -212,19 +201,7 @@ __device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], cons
 #pragma unroll
     for (int k = 0; k < TEAM_EPT; k++)
         if (dst[k] != TEAM_EMPTY) mout[slot[k]] = word[k];
-#ifdef FORA_PROBE_STORE2 // (probe) one more store per message whose lanes write consecutive words (1) / four runs of 16 words (2)
-    {
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[0]) & ~63u, lane_ = threadIdx.x & 63u;
-#pragma unroll
-        for (int k = 0; k < TEAM_EPT; k++)
-            mout[(size_t)80000000 + base + k * 4096 + (FORA_PROBE_STORE2 == 1 ? lane_ : (lane_ >> 4) * 1024 + (lane_ & 15u) + 5)] = word[k];
-    }
-#endif
-#ifdef FORA_PROBE_STORE // (probe) what does ONE MORE scattered 4-byte store per message cost?  (a second copy, FORA_PROBE_STORE words further on)
-#pragma unroll
-    for (int k = 0; k < TEAM_EPT; k++)
-        if (dst[k] != TEAM_EMPTY) mout[(size_t)(FORA_PROBE_STORE) + slot[k]] = word[k];
-#endif
+    diag::team_emit_probe(word, dst, slot, mout, TEAM_EMPTY); // (nothing in the product build)
 }
 
 // grid = nteams * T workgroups of TEAM_THREADS, all resident (one per CU); dynamic LDS = 8 * (R + 1) bytes.
@@ -358,9 +335,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
         bool final_round = false;
         if (fresh(tid0) == 0) s_rsvovf = 0;
 
-#ifdef FORA_STAMPS_LEVELS
-        long long lv_t_ = clock64();
-#endif
+        TSTAMP_LEVEL_DECL
         for (uint32_t L = 0;; L++) {
             const int tid = fresh(tid0), lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6); // this level's copies (see fresh())
             // ================= consume: the messages of the previous level that are addressed to me
@@ -389,11 +364,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 if ((uint32_t)lane < T) wv = __hip_atomic_load(&cwin[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sc1: past L1, like every load of handed-over data)
                 const unsigned long long ready = __ballot((uint32_t)lane < T && (uint32_t)(wv >> 40) == tagp) & ~donemask;
                 if (!ready) {
-#ifdef FORA_STAMPS
-                    { const long long w0_ = clock64(); __builtin_amdgcn_s_sleep(2); ts_a_[8] += (unsigned long long)(clock64() - w0_) + 40; } // (pure waiting inside the consume; + the poll itself)
-#else
-                    __builtin_amdgcn_s_sleep(2);
-#endif
+                    TSTAMP_SLEEP(8, 2, 40); // s_sleep(2) (stamps builds: charged to slot 8 as pure waiting inside the consume, + the poll itself)
                     if ((++spins & 255u) == 0) { // (rare: its operands are read here, not held through the loop)
                         const TeamArgs ar = team_args();
                         uint32_t *ctl = ar->ctl;
@@ -465,17 +436,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         for (int u = 0; u < MPL; u++)
                             vv[k][u] = __hip_atomic_load((const unsigned long long *)&tb[left[k] > (uint32_t)u ? (mw[k][u] >> TEAM_LBITS) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-#ifdef FORA_PROBE_GATHER // what does ONE MORE scattered 8-byte gather per message cost?  (another line of the same table; adds 0)
 #pragma unroll
-                    for (int k = 0; k < CU; k++) {
-                        const uint64_t *tb = tin + (uint64_t)srcm[k] * tstride;
+                    for (int k = 0; k < CU; k++) // (fora_diag.h: one more gather per message in the gather-probe build, nothing otherwise)
 #pragma unroll
-                        for (int u = 0; u < MPL; u++) {
-                            const uint64_t xa = __hip_atomic_load((const unsigned long long *)&tb[left[k] > (uint32_t)u ? ((mw[k][u] >> TEAM_LBITS) ^ 8u) : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            vv[k][u] += xa >> 63; // (values are below 2^62)
-                        }
-                    }
-#endif
+                        for (int u = 0; u < MPL; u++)
+                            vv[k][u] += diag::team_gather_probe(tin + (uint64_t)srcm[k] * tstride, mw[k][u] >> TEAM_LBITS, left[k] > (uint32_t)u);
 #pragma unroll
                     for (int k = 0; k < CU; k++)
 #pragma unroll
@@ -488,16 +453,18 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     if (lane == 63) s_F = fs; // nodes the team popped in the level before
                 }
                 __syncthreads();
-#ifdef FORA_STAMPS_SMALL
-                ts_on_ = s_F <= (uint32_t)(FORA_STAMPS_SMALL) && s_F > 0;
-                if (ts_on_) ts_a_[4]++; // (levels counted)
-#endif
+                TSTAMP_GATE(s_F);
                 TSTAMP(0);
-                if (s_abort) return;
+                const TeamArgs af = team_args();
+                bool quit = s_abort != 0;
+                if (af->abort_level && L == af->abort_level) { // tests (option team_abort_level): give up in the middle of a slot, as after a time-out
+                    if (tid == 0) { __hip_atomic_store(&af->ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicOr(af->err, ERR_TEAM_TIMEOUT); }
+                    quit = true;
+                }
+                if (quit) return;
                 const uint32_t F = s_F;
                 if (F) nlev++;
                 peak = max(peak, F);
-                const TeamArgs af = team_args();
                 const uint32_t tail_max = af->tail_max;
                 final_round = F == 0 || (tail_max && F <= tail_max && (peak > tail_max || af->tail_always));
             }
@@ -791,11 +758,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                     fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)fin);
                     if (fin) break;
-#ifdef FORA_STAMPS
-                    if (k == TEAM_EMPTY) { const long long w0_ = clock64(); __builtin_amdgcn_s_sleep(1); ts_a_[9] += (unsigned long long)(clock64() - w0_) + 30; continue; }
-#else
-                    if (k == TEAM_EMPTY) { __builtin_amdgcn_s_sleep(1); continue; }
-#endif
+                    if (k == TEAM_EMPTY) { TSTAMP_SLEEP(9, 1, 30); continue; }
                     const TeamArgs a = team_args(); // (a heavy chunk is 256 edges: two scalar loads are nothing beside it)
                     uint32_t *mout = a->msg + ((uint64_t)team * 2 + (g & 1u)) * cap_total;
                     const uint32_t *colt = a->colt;
@@ -873,9 +836,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 logbase += s_ncross; // (s_fill / s_ncross are zeroed in the sweep of the next level: behind the barrier that closes its consume)
             }
             TSTAMP(5);
-#ifdef FORA_STAMPS_LEVELS
-            if (tid == 0) { const long long n_ = clock64(); atomicAdd(&team_args()->stamps[L < 31 ? L : 31], (unsigned long long)(n_ - lv_t_)); lv_t_ = n_; }
-#endif
+            TSTAMP_LEVEL(L);
             g++;
         }
         // ---- the slot's counters (algo.h:992 rsum bookkeeping)

@@ -507,6 +507,7 @@ static void ivec_push(ivec *v, int32_t x) {
 }
 
 /* algo.h:1020-1093 forward_local_update_linear_topk. */
+static int64_t topk_push_pops, topk_push_relax; /* work counters of push_fifo_topk (bench.py's roofline of the top-k push; single-threaded use) */
 static void push_fifo_topk(int32_t n, const int64_t *row_ptr, const int32_t *col, int32_t s,
                            double *rsum, double rmax, double lowest_rmax, double alpha, smap *reserve,
                            smap *residue, ivec *forward_from, unsigned char *in_forward,
@@ -526,6 +527,7 @@ static void push_fifo_topk(int32_t n, const int64_t *row_ptr, const int32_t *col
             int64_t out_neighbor = row_ptr[v + 1] - row_ptr[v];
             double v_residue = residue->val[v];
             residue->val[v] = 0;
+            topk_push_pops++; topk_push_relax += out_neighbor;
             smap_add(reserve, v, v_residue * alpha); /* :1043-1048 */
             *rsum -= v_residue * alpha;              /* :1050 */
             if (out_neighbor == 0) {                 /* :1051-1064 */
@@ -676,6 +678,39 @@ int orc_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *
     if (ppr_out) memcpy(ppr_out, ppr.val, sizeof(double) * (size_t)n);
     free(all); free(tmp); free(f1); free(f2); free(rw_counter); free(forward_from.a);
     smap_free(&reserve); smap_free(&residue); smap_free(&ppr);
+    return 0;
+}
+
+/* The pushes of the first `rounds` rounds of fora_query_topk_new (query.h:1001-1041) for one source, without the walks
+ * between them: forward_local_update_linear_topk works on reserve / residue / forward_from only, so its work does not
+ * depend on the walks -- only the NUMBER of rounds does (the stop test, :1030), and the caller passes the number its
+ * own run took.  Returns the pops and edge relaxations of those pushes: the algorithmic counts of bench.py's roofline
+ * entry for the top-k configuration. */
+int orc_topk_push_counts(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s, int32_t k,
+                         double epsilon, double alpha, double rmax_scale, int32_t rounds, int64_t *pops, int64_t *relax) {
+    if (k == 0) k = 500;
+    const double min_delta = 1.0 / n, init_delta = 1.0 / k / 10, pfail = 1.0 / n / n;
+    const double lowest_delta_rmax = epsilon * sqrt(min_delta / 3 / m / log(2 / pfail));
+    double delta = init_delta, rsum = 1.0;
+    smap reserve, residue;
+    smap_init(&reserve, n); smap_init(&residue, n);
+    ivec forward_from = {0, 0, 0};
+    ivec_push(&forward_from, s);
+    smap_insert(&residue, s, rsum);
+    unsigned char *f1 = (unsigned char *)malloc((size_t)n), *f2 = (unsigned char *)malloc((size_t)n);
+    topk_push_pops = 0; topk_push_relax = 0;
+    for (int32_t r = 0; r < rounds && delta >= min_delta; r++) {
+        double rmax, omega;
+        orc_fora_topk_setting(m, epsilon, delta, pfail, rmax_scale, &rmax, &omega);
+        if (row_ptr[s + 1] == row_ptr[s]) break; /* :1007-1011 */
+        push_fifo_topk(n, row_ptr, col, s, &rsum, rmax, lowest_delta_rmax, alpha, &reserve, &residue, &forward_from, f1, f2);
+        if (delta <= min_delta) break;
+        delta = delta / 4.0 > min_delta ? delta / 4.0 : min_delta;
+    }
+    if (pops) *pops = topk_push_pops;
+    if (relax) *relax = topk_push_relax;
+    free(f1); free(f2); free(forward_from.a);
+    smap_free(&reserve); smap_free(&residue);
     return 0;
 }
 

@@ -121,6 +121,11 @@ int orc_topk_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *
                    const int32_t *rw_idx, const uint64_t *off, const uint64_t *cnt,
                    int32_t *ids, double *scores, int32_t *rounds, double *ppr_out);
 
+/* Pops and edge relaxations of the pushes of the first `rounds` rounds of the --opt top-k driver for one source
+ * (algo.h:1020-1093 under query.h:1001-1041), without the walks between them. */
+int orc_topk_push_counts(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s, int32_t k,
+                         double epsilon, double alpha, double rmax_scale, int32_t rounds, int64_t *pops, int64_t *relax);
+
 /* ---- top-k with bounds (get_topk without --opt): query.h:909-969, :639-750, algo.h:1096-1261 ---- */
 double orc_calculate_lambda(double rsum, double pfail, double upper_bound, long total_rw_num);
 int orc_topk_bound_query(int32_t n, int64_t m, const int64_t *row_ptr, const int32_t *col, int32_t s,

@@ -247,6 +247,14 @@ def topk_query(g, s, k, epsilon, alpha=0.2, rmax_scale=1.0, seed=0, index=None, 
     return ids, sc, rounds.value, ppr
 
 
+def topk_push_counts(g, s, k, epsilon, rounds, alpha=0.2, rmax_scale=1.0):
+    """(pops, relaxations) of the FIFO pushes of the first `rounds` rounds of the --opt top-k driver (no walks)."""
+    pops, relax = C.c_int64(0), C.c_int64(0)
+    lib().orc_topk_push_counts(C.c_int32(g.n), C.c_int64(g.m), _p(g.row_ptr), _p(g.col), C.c_int32(s), C.c_int32(k),
+                               _d(epsilon), _d(alpha), _d(rmax_scale), C.c_int32(int(rounds)), C.byref(pops), C.byref(relax))
+    return int(pops.value), int(relax.value)
+
+
 def power_iteration(g, s, alpha=0.2, iters=100):
     ppr = np.zeros(g.n, dtype=np.float64)
     lib().orc_power_iteration(C.c_int32(g.n), _p(g.row_ptr), _p(g.col), C.c_int32(s), _d(alpha),

@@ -59,3 +59,31 @@ def test_c_binding_compiles_and_fails_loudly_without_gpu():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode == 77, (r.returncode, r.stderr)
+
+
+def _build_flag(path, name):
+    lib = ctypes.CDLL(path)
+    lib.fora_hip_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    v = ctypes.c_int64(-1)
+    assert lib.fora_hip_get_option(None, name.encode(), ctypes.byref(v)) == 0  # a property of the build: no context, no GPU
+    return v.value
+
+
+def test_shipped_library_is_not_a_diagnostic_build():
+    """fora_amd/csrc/fora_diag.h: every FORA_PROBE_* / FORA_STAMPS* / FORA_DG_FAKE_* macro turns the library into a
+    diagnostic build (some of them compute wrong results on purpose).  The product library must be none of them, and the
+    kernel bodies must carry no diagnostic #ifdef of their own -- the hooks live in fora_diag.h."""
+    from fora_amd import capi
+    assert _build_flag(capi.lib_path(), "diag_build") == 0
+    assert _build_flag(capi.lib_path(), "test_paths") == 0
+    test_lib = os.path.join(ROOT, "fora_amd", "libfora_hip_test.so")
+    assert _build_flag(test_lib, "diag_build") == 0 and _build_flag(test_lib, "test_paths") == 1
+    for f in ("fora_kernels.h", "fora_team.h", "fora_hip.hip"):
+        text = open(os.path.join(ROOT, "fora_amd", "csrc", f)).read()
+        for pat in ("FORA_PROBE_", "FORA_DG_FAKE", "ifdef FORA_STAMPS", "defined(FORA_STAMPS"):
+            assert pat not in text, (f, pat)
+    # ... and a context-bound option still needs a context
+    lib = ctypes.CDLL(capi.lib_path())
+    lib.fora_hip_get_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    v = ctypes.c_int64(0)
+    assert lib.fora_hip_get_option(None, b"team_fallbacks", ctypes.byref(v)) != 0

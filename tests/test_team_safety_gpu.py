@@ -69,6 +69,44 @@ def test_forced_timeout_falls_back_to_bucketed(engine, oracle, small):
     engine.reset_options()
 
 
+@pytest.mark.parametrize("level", [1, 2, 4])
+def test_abort_in_mid_flight_falls_back_and_leaves_no_trace(engine, oracle, small, level):
+    """`team_timeout_ms=0` aborts before k_push_team has written anything.  The test knob `team_abort_level`
+    makes every member abandon the launch when its slot reaches that level -- partial residue / reserve slabs, reserve
+    logs, message buffers and tagged count words are left behind.  The call must still return the twin's bits (run again
+    through the bucketed kernels), and the NEXT team launch -- same workspace -- must return them too."""
+    g = small
+    engine.clear_index()
+    engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+    engine.set_params(epsilon=0.5, seed=SEED)
+    rmax, omega = engine.get_params()
+    srcs = pick_sources(g, 40, 311)  # more slots than teams: every team is in the middle of a slot, others are untouched
+    want = [oracle.twin_push(g, int(s), rmax) for s in srcs[:6]]
+    engine.set_option("team", 1)
+    try:
+        fb0 = engine.get_option("team_fallbacks")
+        engine.set_option("team_abort_level", level)
+        engine.reset_timing()
+        rsv, res, st = engine.push(srcs)
+        assert engine.get_option("team_fallbacks") == fb0 + 1
+        assert engine.timing()["push_team_launches"] == 0 and engine.timing()["push_expand_launches"] > 0
+        for i, t in enumerate(want):
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+        engine.reset_options()  # ends the back-off, clears the knob; the workspace (and whatever the abort left in it) stays
+        engine.set_option("team", 1)
+        engine.reset_timing()
+        rsv2, res2, st2 = engine.push(srcs)
+        assert engine.timing()["push_team_launches"] >= 1 and engine.get_option("team_fallbacks") == fb0 + 1
+        assert (rsv2 == rsv).all() and (res2 == res).all()
+        ppr, _, stq = engine.query_fix(srcs[:2], want_residue=False)
+        for i in range(2):
+            w, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED)
+            assert (ppr[i] == w).all() and stq[i]["n_walks"] == wst["n_walks"]
+    finally:
+        engine.reset_options()
+
+
 @pytest.fixture(scope="module")
 def ws_graph(oracle):
     from fora_amd import synth

@@ -29,8 +29,13 @@ def main():
             res[k][c + "_dispatches"] = n
             res[k][c + "_bytes_per_launch"] = v * 1024.0 / max(1, n)
             res[k][c + "_bytes_total"] = v * 1024.0
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each (tools/profile_bench.sh), of ONE bench.py step of this "
+                    "workload; KiB per dispatch summed per kernel; raw counters (calibration: profiles/r04_pmc_calibration.txt -- "
+                    "FETCH_SIZE counts 64 B per request, streamed reads move 128 B per request: true reads lie between x1 and x2)")
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
+        if not isinstance(v, dict):
+            continue
         print(k, {a: round(b) for a, b in v.items() if a.endswith("per_launch")})
 
 
