@@ -67,6 +67,7 @@ struct Tunables {
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
     int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
+    int64_t acc_group = 0;       // wide accumulate: bins per workgroup (0: by the launch's size, 1 ... 8; tests force 1 / 3 / 16)
     int64_t team_abort_level = 0; // tests: every team abandons its launch (as after a time-out) when a slot reaches this level -- an abort in mid-flight: partial slabs, logs, message buffers, tagged words
     int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
     int64_t team_coop = 0;       // k_push_team launch: 0 (default) plain launch behind an occupancy check (occupancy x CUs >= grid, team_fits); 1: hipLaunchCooperativeKernel.  Measured on ROCm 7.2 / MI355X (round 5): the cooperative
@@ -83,7 +84,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_abort_level", &Tunables::team_abort_level, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_abort_level", &Tunables::team_abort_level, false}, {"acc_group", &Tunables::acc_group, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -709,6 +710,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.row_split = c->d_row_split;
     d.npass = c->pbins > 0 ? (c->nbins + c->pbins - 1) / c->pbins : 1;
     d.pass = 0;
+    d.acc_group = 1; // (set per launch: acc_grid)
     d.tiny_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.tiny, 0), 1023); // 512: ws accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193 (the crossing list of the small-bucket path holds 1024)
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
@@ -801,6 +803,19 @@ int check_dev_err(fora_ctx *c) {
 // launches, a host round trip per level would cost more.
 static inline size_t tail_lds(const Dev &d) { return d.tail_hubs && d.col_hub ? (size_t)d.hubs * 8 : 0; } // k_push_tail's dynamic LDS
 
+// Wide accumulate: bins per workgroup (Dev::acc_group) and the grid's x size.  One bin per workgroup for query / power-iteration
+// calls; the top-k drivers on wide graphs (many slots, rounds that touch a handful of bins: 94 k workgroups per launch at
+// Twitter-2010 size, nearly all of them empty) take up to 8 consecutive bins of a slot per workgroup -- k_accum<false> 58 -> 39 ms
+// per 125-source step, 301 -> 318 q/s.  (For LJ-sized queries, same 94 k workgroups but mostly busy ones: 211.7 ms grouped against
+// 206.6 -- the bins of a group run one after the other --, hence not there.)
+static unsigned acc_grid(const fora_ctx *c, Dev &dp, int nq) {
+    const uint64_t pairs = (uint64_t)dp.bin_cnt * (uint64_t)std::max(1, nq);
+    const uint64_t want = (uint64_t)std::max(1, c->prop.multiProcessorCount) * 24; // workgroups that keep the chip busy with one per CU at a time
+    uint32_t g = c->bk_div > 1 ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pairs / want, 1), 8) : 1u;
+    if (c->opt_.acc_group > 0) g = (uint32_t)std::min<int64_t>(c->opt_.acc_group, ACC_GROUP_MAX);
+    dp.acc_group = g;
+    return (unsigned)((dp.bin_cnt + g - 1) / g);
+}
 int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, int level_cap = 0, bool round_start = false) {
     const int nq = d.nq;
     if (round_start && c->binned && level_cap <= 0 && d.rounds <= 1 && c->opt_.tail != 0) {
@@ -884,7 +899,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 }
                 ev_end(c, h);
                 h = ev_begin(c, 6);
-                if (d.wide) hipLaunchKernelGGL((k_accum<false, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L);
+                if (d.wide) { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<false, true>), dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L); }
                 else hipLaunchKernelGGL((k_accum<false, false>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
                 ev_end(c, h);
             }
@@ -1114,7 +1129,7 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
                 if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_HUGE), 0, c->stream, dp);
                 else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
-                hipLaunchKernelGGL((k_accum<true, true>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0);
+                { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<true, true>), dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0); }
             }
     }
     const bool dg = c->binned && !d.wide && d.dg.colp && c->opt_.walk_dg != 0; // narrow layout: one gather per step over the degree-grouped copy
@@ -1623,6 +1638,9 @@ static int build_quad_copies(fora_ctx *c) {
     const size_t n = (size_t)c->n;
     std::vector<uint64_t> ri4(n);
     uint64_t q = 0;
+    // (Round 6, measured and dropped: rows placed so that each touches as few 64-byte lines as its length allows -- a row that would
+    // straddle one line more than ceil(quads / 4) started at the next line.  LJ-sized bin kernel 315.4 / 314.8 ms against 320.7 / 314.5
+    // back to back, Twitter-2010-sized 593.6 / 592.9 against 594.5 / 585.6: what a quad load costs is not the lines its row touches.)
     for (size_t v = 0; v < n; v++) {
         const uint64_t dg = (uint64_t)(c->h_row_ptr[v + 1] - c->h_row_ptr[v]);
         ri4[v] = (q << 24) | std::min<uint64_t>(dg, DEG_SAT);

@@ -253,6 +253,9 @@ struct Dev {
     uint32_t hubs, hub_min;
     uint32_t tail_hubs;     // != 0: k_push_tail sums the increments for hubs in LDS too (its launches pass hubs * 8 bytes of dynamic LDS)
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
+    uint32_t acc_group; // k_accum (wide layouts): consecutive bins of a slot per workgroup (>= 1).  The workgroup reads their counts in one coalesced trip and
+                        // skips the bins that have nothing to do: 94 k one-bin workgroups per launch cost 0.74 ms when nearly all of them are empty (sparse levels,
+                        // top-k rounds)
     uint32_t *fl[2];        // [slot][n] frontier node lists, ping-pong by level parity
     uint32_t *fl_count[2];  // [slot]
     // [slot][segq_cap] increment of the node at frontier position i, ping-pong like fl: the accumulate of level L
@@ -1338,8 +1341,16 @@ __global__ void __launch_bounds__(TAIL_THREADS, FORA_TAIL_WPE) k_push_tail(Dev d
 // (d.pop_next = 0 on the last level of a capped run leaves it alone): its residue is in registers, so the slab word is
 // stored as 0 (algo.h:984-985) and (node, residue) is appended at a rank that follows the NODE ORDER inside the bin.
 // The bin kernel of the next level finishes the pop with dense lanes and never gathers a residue.
+// (The argument struct is read through the kernarg segment -- constant address space: scalar loads -- so that the wide kernel can launder the
+// pointer per bin: by value, the loop over a workgroup's bins hoisted the ~40 fields the body reads into SGPRs for the whole launch, 39 of them spilled.)
+typedef const __attribute__((address_space(4))) Dev &DevRef;
+__device__ __forceinline__ const __attribute__((address_space(4))) Dev *dev_args() {
+    auto p = (const __attribute__((address_space(4))) Dev *)__builtin_amdgcn_kernarg_segment_ptr(); // (Dev is the kernel's first argument)
+    asm volatile("" : "+s"(p));
+    return p;
+}
 template <bool TO_PPR, bool WIDE>
-__global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum(Dev d, int L) {
+__device__ __forceinline__ void accum_bin(DevRef d, int L, const int lb, const int q) { // lb: bin inside the pass
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT; // bits of a local target
     constexpr uint32_t BSZ = 1u << BS;
     constexpr int AT = WIDE ? ACC_THREADS_WIDE : ACC_THREADS;
@@ -1352,8 +1363,7 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     __shared__ uint32_t s_list[TO_PPR ? 1 : 1024];
     __shared__ uint32_t s_nlist;
     __shared__ uint32_t s_scnt[MAX_SUB], s_total, s_ovn, s_din, s_ndef;
-    const int lb = blockIdx.x, q = blockIdx.y; // lb: bin inside the pass; b: bin of the graph
-    const int b = d.bin_lo + lb;
+    const int b = d.bin_lo + lb; // bin of the graph
     const int par = L & 1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t slab = (uint64_t)q * d.n;
@@ -1684,6 +1694,46 @@ __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum
     }
     STAMP(20);
     STAMP_FLUSH(16);
+    }
+}
+
+// grid = (ceil(bins of the pass / G), nq) with G = Dev::acc_group bins per workgroup (narrow layout: always 1).
+constexpr int ACC_GROUP_MAX = 16;
+template <bool TO_PPR, bool WIDE>
+__global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum(Dev d, int L) {
+    const int q = blockIdx.y;
+    if (!WIDE) { accum_bin<TO_PPR, WIDE>(*dev_args(), L, (int)blockIdx.x, q); return; }
+    const uint32_t G = max(d.acc_group, 1u);
+    // which of my G bins have anything to do?  Their sub-bucket counts are one contiguous stretch: a coalesced trip for all of them
+    constexpr int AT = WIDE ? ACC_THREADS_WIDE : ACC_THREADS;
+    constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT;
+    __shared__ uint32_t s_gbusy[ACC_GROUP_MAX];
+    const uint32_t lb0 = blockIdx.x * G;
+    const uint32_t nb = min(G, (uint32_t)d.bin_cnt - lb0);
+    if (G > 1) { // (uniform)
+        const int par = L & 1;
+        if (threadIdx.x < (uint32_t)ACC_GROUP_MAX) s_gbusy[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t sub = d.sub;
+        const uint32_t *cnts = d.bk_count + ((uint64_t)q * d.pbins + lb0) * sub;
+        for (uint32_t i = threadIdx.x; i < nb * sub; i += AT)
+            if (cnts[i]) s_gbusy[i / sub] = 1u; // (benign race: every writer stores 1)
+        if (threadIdx.x < nb) { // the other reasons a bin may have work (see accum_bin): overflow entries, hub sums, the dangling mass, deferred nodes
+            const uint32_t b = (uint32_t)d.bin_lo + lb0 + threadIdx.x;
+            bool busy = TEST_PATHS && !TO_PPR && d.defer_k;
+            if (!TO_PPR) {
+                busy = busy || d.ov_bin[par][(uint64_t)q * d.nbins + b] != 0;
+                busy = busy || ((uint32_t)d.src[q] >> BS) == b; // (the dangling mass of the level, if any, lands in the source's bin)
+                if (d.col_hub && d.fl_count[par][q * CSTRIDE] >= d.hub_min) busy = busy || d.hub_first[b + 1] > d.hub_first[b];
+            }
+            if (busy) s_gbusy[threadIdx.x] = 1u;
+        }
+        __syncthreads();
+    }
+    for (uint32_t g = 0; g < nb; g++) {
+        if (G > 1 && !s_gbusy[g]) continue; // (uniform)
+        accum_bin<TO_PPR, WIDE>(*dev_args(), L, (int)(lb0 + g), q); // (a fresh look at the arguments per bin: nothing rides through the loop)
+        if (g + 1 < nb) __syncthreads(); // the next bin reuses the LDS of this one
     }
 }
 

@@ -434,6 +434,46 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
+@pytest.mark.parametrize("group", [1, 3, 8, 16])
+def test_wide_accumulate_bin_groups_bit_exact(engine, oracle, small_dangling, group):
+    """k_accum of the wide layouts takes `acc_group` consecutive bins of a slot per workgroup (round 6: the workgroup reads their
+    counts in one trip and skips the bins with nothing to do -- overflow entries, hub sums, the dangling mass and walk results
+    included).  Same bits for any group size: push, indexed query (k_accum<true, true>) and top-k against the twin."""
+    g = small_dangling
+    engine.set_option("force_wide", 1)
+    engine.set_option("acc_group", group)
+    engine.set_option("tail", 0)   # every level through the bucketed kernels
+    engine.set_option("team", 0)
+    try:
+        rmax, omega = _load(engine, g, epsilon=0.5)
+        srcs = np.concatenate([pick_sources(g, 6, 191), pick_sources(g, 1, 192, want_dangling=True)])
+        rsv, res, st = engine.push(srcs)
+        for i, s in enumerate(srcs):
+            t = oracle.twin_push(g, int(s), rmax)
+            assert (res[i] == t["residue"]).all() and (rsv[i] == t["reserve"]).all()
+            assert st[i]["pops"] == t["pops"] and st[i]["relax"] == t["relax"] and st[i]["levels"] == t["levels"]
+        engine.set_option("bkcap", 200)  # ... with overflow entries in some bins
+        rsv2, res2, _ = engine.push(srcs)
+        assert (rsv2 == rsv).all() and (res2 == res).all()
+        engine.set_option("bkcap", 0)
+        engine.build_index()
+        idx = engine.get_index()
+        ppr, _, stq = engine.query_fix(srcs[:3], with_idx=True, want_residue=False)
+        for i in range(3):
+            want, _, wst = oracle.twin_query(g, int(srcs[i]), rmax, omega, seed=SEED, index=idx)
+            assert (ppr[i] == want).all() and stq[i]["n_walks"] == wst["n_walks"]
+        engine.clear_index()
+        engine.set_params(epsilon=0.5, opt=True, seed=SEED)
+        ids, sc, rounds = engine.topk(srcs[:2], 50, epsilon=0.5)
+        for i in range(2):
+            wid, wsc, wr, _ = oracle.twin_topk_query(g, int(srcs[i]), 50, 0.5, seed=SEED)
+            assert rounds[i] == wr and (ids[i] == wid).all() and (sc[i] == wsc).all()
+    finally:
+        engine.reset_options()
+        engine.clear_index()
+        engine.set_graph(g.n, g.m, g.row_ptr, g.col)
+
+
 @pytest.mark.parametrize("size,tail,xcd,tmax,log", [(0, 0, 1, 0, -1), (0, -1, 1, 0, -1), (4, 0, 1, 0, 0), (4, 64, 0, 0, -1), (16, 300, 1, 0, 40),
                                                     (32, 0, 1, 0, -1), (32, 2000, 0, 0, 7), (1, 16, 1, 3, 1000), (8, 1, 1, 1, -1), (2, 0, 2, 0, 100)])
 @pytest.mark.parametrize("gname", ["small_dangling", "small"])

@@ -17,4 +17,4 @@ for k, v in d.get("configs", {}).items():
     if isinstance(v, dict): print(k, "%.1f q/s" % v.get("value", -1), "frac", (v.get("roofline") or {}).get("frac"), v.get("error"))
 print(d["accuracy"]["holds"], d["accuracy"]["linf_abs_err"], d["cpu_baseline"]["value"], d.get("cpu_baseline_all_cores", {}).get("value"))
 PY
-bash tools/profile_bench.sh r05_ws > gpurun_out/prof_r05_ws.log 2>&1; head -9 gpurun_out/prof_r05_ws/kernel_stats.csv | cut -c1-150; cat gpurun_out/prof_r05_ws/pmc_summary.txt | cut -c1-200
+bash tools/profile_bench.sh r06_ws > gpurun_out/prof_r06_ws.log 2>&1; head -9 gpurun_out/prof_r06_ws/kernel_stats.csv | cut -c1-150; cat gpurun_out/prof_r06_ws/pmc_summary.txt | cut -c1-200
