@@ -190,7 +190,11 @@ constexpr int TEAM_MAXGROUPS = FORA_TEAM_MAXGROUPS; // 64-id groups of a member 
 // (Measured twice and dropped, rounds 4 and 5: the chunk's messages sorted by destination in a wave-private LDS stage --
 // counting sort over the <= 32 destinations, one fill-counter atomic per (chunk, destination) -- and stored with consecutive
 // lanes on consecutive words of a run: 82-84 ms against 75 in round 4, 51.9 against 50.9 in round 5 (both without hub sums,
-// whose LDS the stage needs): the stage's LDS round trips cost what the 4 x fewer write requests save.)
+// whose LDS the stage needs): the stage's LDS round trips cost what the 4 x fewer write requests save.
+// Round 6, a third form without any sort: per destination a RING of 64-word blocks in LDS (16 KB), a message written to the ring
+// entry of its bucket position, the block's 64th writer (a returning LDS count) flushing it with one coalesced 256-byte store, ring
+// blocks re-armed by their flush -- bit-exact (24 team tests), 82.9 ms against 45.8: three more LDS operations per message and
+// waves waiting for ring blocks cost twice what the scattered stores do.  Messages leave the CU as scattered 4-byte stores.)
 __device__ __forceinline__ void team_emit(const uint32_t (&word)[TEAM_EPT], const uint32_t (&dst)[TEAM_EPT], uint32_t *s_fill, uint32_t *mout) {
     uint32_t slot[TEAM_EPT];
 #pragma unroll
