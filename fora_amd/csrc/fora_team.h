@@ -235,9 +235,11 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
     // out-degrees of the local ids this thread sweeps (it * 1024 + tid), 16 bits each: they never change
     uint32_t dgp[(TEAM_NIT + 1) / 2], thh[TEAM_NIT];
     bool same_xcd;
+    uint32_t hub_tg0; // owner << 15 | local id of hub `tid` (the first TEAM_THREADS hubs: a register instead of a load at every level's end)
     {
         const TeamArgs a = team_args();
         T = a->T; R = a->R; H = a->H;
+        hub_tg0 = (uint32_t)tid0 < H ? a->hubtgt[tid0] : 0u;
         if (a->xcd) { // blocks b and b + 8 share an XCD (observed, not promised): a team = T blocks of one residue class
             const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3; // per: blocks per class, a multiple of T
             team = x * (per / T) + j / T;
@@ -568,10 +570,22 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         base += (uint32_t)__popcll(mk);
                     }
                 }
-                for (uint32_t l = tid; l < R; l += TEAM_THREADS) { // (same thread as above for every l)
-                    const uint32_t v = l2n[l];
-                    if (v != TEAM_EMPTY) residue[v] = res[l];
-                    res[l] = 0;
+                { // (same thread as above for every l)  All node ids of the thread's local ids first, then the stores: one round trip for the
+                  // whole range instead of one per 1024 ids (round 6: the hand-over was a chain of ~30 dependent trips per slot)
+                    uint32_t lv[TEAM_NIT];
+#pragma unroll
+                    for (int it = 0; it < TEAM_NIT; it++) {
+                        const bool in = (uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R; // (scalar)
+                        lv[it] = in ? l2n[it * TEAM_THREADS + tid] : TEAM_EMPTY;
+                    }
+#pragma unroll
+                    for (int it = 0; it < TEAM_NIT; it++) {
+                        if ((uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R) {
+                            const uint32_t l = it * TEAM_THREADS + tid;
+                            if (lv[it] != TEAM_EMPTY) residue[lv[it]] = res[l];
+                            res[l] = 0;
+                        }
+                    }
                 }
                 if (tid == 0) { // (the same thread that may have handed the spare id over)
                     if (me == src_owner && src_spare) residue[src] = res[R];
@@ -600,10 +614,22 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                 const bool ovf = s_rsvovf != 0;
                 uint64_t *rsvl = a->rsvl + ((uint64_t)team * T + me) * R;
                 uint64_t *ppr = a->ppr + slab;
-                for (uint32_t l = tid; l < R; l += TEAM_THREADS) {
-                    uint64_t rs = res[l];
-                    if (ovf) { const uint64_t o = rsvl[l]; if (o) { rs += o; rsvl[l] = 0; } }
-                    if (rs) { ppr[l2n[l]] = rs; res[l] = 0; }
+                {
+                    uint32_t lv[TEAM_NIT];
+#pragma unroll
+                    for (int it = 0; it < TEAM_NIT; it++) {
+                        const bool in = (uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R; // (scalar)
+                        lv[it] = in ? l2n[it * TEAM_THREADS + tid] : TEAM_EMPTY;
+                    }
+#pragma unroll
+                    for (int it = 0; it < TEAM_NIT; it++) {
+                        if ((uint32_t)it * TEAM_THREADS + (uint32_t)wid * 64u < R) {
+                            const uint32_t l = it * TEAM_THREADS + tid;
+                            uint64_t rs = res[l];
+                            if (ovf) { const uint64_t o = rsvl[l]; if (o) { rs += o; rsvl[l] = 0; } }
+                            if (rs) { ppr[lv[it]] = rs; res[l] = 0; }
+                        }
+                    }
                 }
                 TSTAMP(6);
                 break;
@@ -818,7 +844,7 @@ __global__ void __launch_bounds__(TEAM_THREADS, TEAM_THREADS * TEAM_WGS_PER_CU /
                         const unsigned long long hv = s_hub[h];
                         if (hv) {
                             s_hub[h] = 0;
-                            const uint32_t tg = hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
+                            const uint32_t tg = h < (uint32_t)TEAM_THREADS ? hub_tg0 : hubtgt[h], ent = s_ncross + 1 + atomicAdd(&s_hubent, 1u);
                             tout[ent] = hv;
                             mout[atomicAdd(&s_fill[tg >> TEAM_LBITS], 1u)] = (tg & TEAM_LMASK) | (ent << TEAM_LBITS);
                         }
