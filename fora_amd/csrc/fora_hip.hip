@@ -67,6 +67,7 @@ struct Tunables {
     int64_t team_hubs = 1024;    // k_push_team: increments for the nodes of largest in-degree are summed per member in LDS, one message per hub and level (0: off); read when the team tables are built
     int64_t tail_hubs = 1;       // k_push_tail: increments for the hubs of the hub copy are summed in LDS (0: every relaxation is an atomic)
     int64_t team_log = -1;       // k_push_team: entries of a member's reserve log per slot (-1: 2^17; 0: none, every pop adds to its accumulator; tests use small values for the mixed case)
+    int64_t slot_major = -1;     // wide layouts: which launches put the slot in blockIdx.x (Dev::slot_major; bits 1 bin kernel, 2 accumulate, 4 indexed walks, 8 walk allocation); -1: by call type and slot count (make_dev); 0: round 5's order
     int64_t acc_group = 0;       // wide accumulate: bins per workgroup (0: by the launch's size, 1 ... 8; tests force 1 / 3 / 16)
     int64_t team_abort_level = 0; // tests: every team abandons its launch (as after a time-out) when a slot reaches this level -- an abort in mid-flight: partial slabs, logs, message buffers, tagged words
     int64_t team_timeout_ms = 500; // k_push_team: a member that has waited this long for its team gives up; the call then runs again through the bucketed kernels (with_retry)
@@ -84,7 +85,7 @@ static const struct { const char *name; int64_t Tunables::*field; bool layout; }
     {"no_split", &Tunables::no_split, true}, {"no_compact", &Tunables::no_compact, false}, {"walk_dg", &Tunables::walk_dg, false}, {"dg_hubs", &Tunables::dg_hubs, false}, {"hubs", &Tunables::hubs, true}, {"hubs_wide", &Tunables::hubs_wide, true}, {"hub_min", &Tunables::hub_min, false}, {"bkcap", &Tunables::bkcap, true},
     {"ovcap", &Tunables::ovcap, true}, {"tiny", &Tunables::tiny, false}, {"xb", &Tunables::xb, false}, {"ax", &Tunables::ax, false},
     {"wx", &Tunables::wx, false}, {"tail", &Tunables::tail, false}, {"tail_always", &Tunables::tail_always, false},
-    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_abort_level", &Tunables::team_abort_level, false}, {"acc_group", &Tunables::acc_group, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
+    {"select_compact", &Tunables::select_compact, false}, {"pipeline", &Tunables::pipeline, false}, {"team", &Tunables::team, true}, {"team_size", &Tunables::team_size, true}, {"team_tail", &Tunables::team_tail, false}, {"team_xcd", &Tunables::team_xcd, false}, {"team_max", &Tunables::team_max, true}, {"team_hubs", &Tunables::team_hubs, true}, {"team_log", &Tunables::team_log, false}, {"topk_bk_div", &Tunables::topk_bk_div, true}, {"quads", &Tunables::quads, false}, {"team_timeout_ms", &Tunables::team_timeout_ms, false}, {"team_abort_level", &Tunables::team_abort_level, false}, {"acc_group", &Tunables::acc_group, false}, {"slot_major", &Tunables::slot_major, false}, {"team_coop", &Tunables::team_coop, false}, {"tail_hubs", &Tunables::tail_hubs, false}, {"rounds", &Tunables::rounds, false}, {"defer", &Tunables::defer, true}, {"defer_min", &Tunables::defer_min, false}, {"round_div", &Tunables::round_div, false},
     {"profile", &Tunables::profile, false}, {"grid", &Tunables::grid, false},
 };
 // knobs that choose another push SCHEDULE (other, equally valid result bits): never taken from the environment -- a stray
@@ -318,7 +319,7 @@ static uint32_t slab_grid_x(const fora_ctx *c, int nq) {
     const int64_t nchunk = ((int64_t)c->n + BLOCK - 1) / BLOCK;
     int64_t x = std::min<int64_t>(1024, std::max<int64_t>(16, 32768 / std::max(1, nq)));
     if (c->opt_.ax > 0) x = c->opt_.ax;
-    return (uint32_t)std::max<int64_t>(1, std::min(x, nchunk));
+    return (uint32_t)std::max<int64_t>(1, std::min<int64_t>(std::min(x, nchunk), 65535)); // (may be a grid's y extent: Dev::slot_major)
 }
 static unsigned walk_grid_x(const fora_ctx *c, int nq) {
     if (c->opt_.wx > 0) return (unsigned)c->opt_.wx;
@@ -711,6 +712,12 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.npass = c->pbins > 0 ? (c->nbins + c->pbins - 1) / c->pbins : 1;
     d.pass = 0;
     d.acc_group = 1; // (set per launch: acc_grid)
+    // Dispatch order of the wide kernels (Dev::slot_major), measured per kernel (profiles/r06_slot_major.txt): slot-major pays for the bin kernel
+    // when a launch holds many slots (LJ-sized, 143-159 slots: 1190 -> 1088 ms per 1000 queries; Twitter-2010-sized, 8 slots: 620 -> 930 ms) and
+    // for the indexed walks of query calls (LJ-sized 760 -> 710 ms, Twitter-2010-sized - 2 %); it loses for the accumulate, the walk allocation
+    // and everything in the top-k drivers (few, sparse slots' worth of work per launch).
+    d.slot_major = c->opt_.slot_major >= 0 ? (uint32_t)c->opt_.slot_major & 15u
+                   : (c->bk_div > 1 ? 0u : (4u | (nq >= 32 ? 1u : 0u)));
     d.tiny_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.tiny, 0), 1023); // 512: ws accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193 (the crossing list of the small-bucket path holds 1024)
     d.fl[0] = c->d_fl[0]; d.fl[1] = c->d_fl[1];
     d.fl_count[0] = c->d_fl_count; d.fl_count[1] = c->d_fl_count ? c->d_fl_count + (size_t)c->B * CSTRIDE : nullptr;
@@ -875,13 +882,14 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 {
                     const size_t hub_lds = dp.col_hub ? (size_t)dp.hubs * 8 : 0;
                     const bool hub = dp.col_hub != nullptr, split = dp.row_split != nullptr, sched = TEST_PATHS && (dp.rounds > 1 || dp.defer_k > 0);
-#define FORA_BIN_LAUNCH(NBV, NT, HUBV, SPLITV, SCHEDV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, SPLITV, SCHEDV>), dim3(xb, nq), dim3(NT), hub_lds, c->stream, dp, L)
+                    const dim3 bgrid = (dp.wide && (dp.slot_major & 1u)) ? dim3(nq, xb) : dim3(xb, nq); // (Dev::slot_major: the slot is the fastest-varying index)
+#define FORA_BIN_LAUNCH(NBV, NT, HUBV, SPLITV, SCHEDV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, SPLITV, SCHEDV>), bgrid, dim3(NT), hub_lds, c->stream, dp, L)
 #if FORA_TEST_PATHS
 #define FORA_BIN_SCHED(NBV, NT) FORA_BIN_LAUNCH(NBV, NT, true, true, true)
 #else
 #define FORA_BIN_SCHED(NBV, NT) (void)0
 #endif
-#define FORA_BIN_QUAD(NBV, NT, HUBV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, false, false, true>), dim3(xb, nq), dim3(NT), hub_lds, c->stream, dp, L)
+#define FORA_BIN_QUAD(NBV, NT, HUBV) hipLaunchKernelGGL((k_pushq_bin<NBV, HUBV, false, false, true>), bgrid, dim3(NT), hub_lds, c->stream, dp, L)
 #define FORA_BIN_PICK(NBV, NT) do { \
                     if (!sched && !split && dp.col4 && NBV > MAX_BINS) { if (hub) FORA_BIN_QUAD(NBV, NT, true); else FORA_BIN_QUAD(NBV, NT, false); break; } \
                     if (sched) FORA_BIN_SCHED(NBV, NT); /* schedule experiments: the everything instantiation (test library only) */ \
@@ -899,7 +907,7 @@ int run_push_levels(fora_ctx *c, const Dev &d, uint64_t *levels_run = nullptr, i
                 }
                 ev_end(c, h);
                 h = ev_begin(c, 6);
-                if (d.wide) { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<false, true>), dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L); }
+                if (d.wide) { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<false, true>), (dp.slot_major & 2u) ? dim3(nq, gx) : dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, L); }
                 else hipLaunchKernelGGL((k_accum<false, false>), dim3(dp.bin_cnt, nq), dim3(ACC_THREADS), 0, c->stream, dp, L);
                 ev_end(c, h);
             }
@@ -1127,9 +1135,10 @@ void launch_walks(fora_ctx *c, const Dev &d, int nq, bool with_idx, uint32_t rou
                 Dev dp = d;
                 dp.bin_lo = lo;
                 dp.bin_cnt = std::min(c->pbins, c->nbins - lo);
-                if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgs, dim3(BIN_THREADS_HUGE), 0, c->stream, dp);
-                else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgs, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
-                { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<true, true>), dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0); }
+                const dim3 wgi = (dp.slot_major & 4u) ? dim3(wgs.y, wgs.x) : wgs;
+                if (c->pbins > MAX_BINS_WIDE) hipLaunchKernelGGL(k_walk_idx<MAX_BINS_HUGE>, wgi, dim3(BIN_THREADS_HUGE), 0, c->stream, dp);
+                else hipLaunchKernelGGL(k_walk_idx<MAX_BINS_WIDE>, wgi, dim3(BIN_THREADS_WIDE), 0, c->stream, dp);
+                { const unsigned gx = acc_grid(c, dp, nq); hipLaunchKernelGGL((k_accum<true, true>), (dp.slot_major & 2u) ? dim3(nq, gx) : dim3(gx, nq), dim3(ACC_THREADS_WIDE), 0, c->stream, dp, 0); }
             }
     }
     const bool dg = c->binned && !d.wide && d.dg.colp && c->opt_.walk_dg != 0; // narrow layout: one gather per step over the degree-grouped copy
@@ -1247,7 +1256,7 @@ int batch_begin(fora_ctx *c, const int32_t *sources, int nq, bool with_idx, int 
     if (!(flags & RUN_PUSH_ONLY)) {
         const uint32_t chunks = slab_grid_x(c, nq);
         h = ev_begin(c, 2);
-        hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
+        hipLaunchKernelGGL(k_walk_alloc<ALLOC_QUERY>, (d.wide && (d.slot_major & 8u)) ? dim3(nq, chunks) : dim3(chunks, nq), dim3(BLOCK), 0, c->stream, d, with_idx ? 1 : 0,
                            (const uint8_t *)nullptr, (uint64_t *)nullptr, (unsigned long long *)nullptr, 0u);
         ev_end(c, h);
         launch_walks(c, d, nq, with_idx, 0u, c->opt ? 1 : 0);
@@ -2210,7 +2219,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             Dev dw = d;
             dw.ppr = c->d_ppr2;
             h = ev_begin(c, 2);
-            hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
+            hipLaunchKernelGGL(k_walk_alloc<ALLOC_TOPK>, (dw.wide && (dw.slot_major & 8u)) ? dim3(nb, chunks) : dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
                                (const uint8_t *)c->d_active, c->d_cursor, (unsigned long long *)nullptr, c->cursor_epoch);
             ev_end(c, h);
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, with_idx ? 1 : 0);
@@ -2373,7 +2382,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
             Dev dw = d;
             dw.ppr = c->d_ppr2;
             h = ev_begin(c, 2);
-            hipLaunchKernelGGL(k_walk_alloc<ALLOC_BOUND>, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
+            hipLaunchKernelGGL(k_walk_alloc<ALLOC_BOUND>, (dw.wide && (dw.slot_major & 8u)) ? dim3(nb, chunks) : dim3(chunks, nb), dim3(BLOCK), 0, c->stream, dw, with_idx ? 1 : 0,
                                (const uint8_t *)c->d_active, c->d_cursor, c->d_round_walks, c->cursor_epoch);
             ev_end(c, h);
             launch_walks(c, dw, nb, with_idx != 0, (uint32_t)round, 0);

@@ -253,6 +253,10 @@ struct Dev {
     uint32_t hubs, hub_min;
     uint32_t tail_hubs;     // != 0: k_push_tail sums the increments for hubs in LDS too (its launches pass hubs * 8 bytes of dynamic LDS)
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
+    uint32_t slot_major; // wide layouts, one bit per kernel (1: k_pushq_bin, 2: k_accum, 4: k_walk_idx, 8: k_walk_alloc): the launch puts the SLOT in blockIdx.x (the fastest-varying
+                         // index of the dispatch order) and the tile / bin / chunk in blockIdx.y: the workgroups in flight at one time then work on the same
+                         // stretch of the graph for many slots, and what they share -- rows of col, degrees, index segments -- is fetched from HBM once and
+                         // hit in L2 by the others (round 6, profiles/r06_slot_major.txt)
     uint32_t acc_group; // k_accum (wide layouts): consecutive bins of a slot per workgroup (>= 1).  The workgroup reads their counts in one coalesced trip and
                         // skips the bins that have nothing to do: 94 k one-bin workgroups per launch cost 0.74 ms when nearly all of them are empty (sparse levels,
                         // top-k rounds)
@@ -736,11 +740,13 @@ template <int NB, bool HUB, bool SPLIT, bool SCHED, bool QUAD = false>
 __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int L) {
     static_assert(!(QUAD && SPLIT), "pass-split rows are read edge by edge");
     constexpr int NT = BinThreads<NB>::value; // workgroup size = frontier entries per tile; BIN_EPT * NT edges per chunk
-    const int q = blockIdx.y;
+    const bool slot_major = NB > MAX_BINS && (d.slot_major & 1u); // (see Dev::slot_major)
+    const int q = slot_major ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = slot_major ? blockIdx.y : blockIdx.x, gx = slot_major ? gridDim.y : gridDim.x; // this workgroup's number among the slot's, and their count
     const int par = L & 1;
     const uint32_t count = d.fl_count[par][q * CSTRIDE];
     const bool first_pass = d.bin_lo == 0; // graphs with more than pbins bins run several bin/accum passes per level
-    if (first_pass && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (first_pass && bx == 0 && threadIdx.x == 0) {
         d.fl_count[par ^ 1][q * CSTRIDE] = 0; // next level's list starts empty
         if (SCHED) d.fl_count[par ^ 1][q * CSTRIDE + 2] = 0; // ... and so does the count of nodes this level defers
         d.ov_count[par ^ 1][q * CSTRIDE] = 0; // consumed by k_accum of the previous level
@@ -748,7 +754,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         if (SCHED && d.rounds > 1 && count > d.qs[q].peak) d.qs[q].peak = count; // k_round_sweep compares the next frontier with it
     }
     constexpr bool WIDE = NB > MAX_BINS;
-    if (WIDE && blockIdx.x == 0 && threadIdx.x == 0) d.tile_ctr[d.launch_par ^ 1][q * CSTRIDE] = 0; // for the next launch
+    if (WIDE && bx == 0 && threadIdx.x == 0) d.tile_ctr[d.launch_par ^ 1][q * CSTRIDE] = 0; // for the next launch
     if (!count) return;
     // hub pre-aggregation (see Dev::col_hub): the same predicate in k_accum decides whether hubsum is read
     extern __shared__ unsigned long long s_hub[]; // [d.hubs] when hubmode
@@ -780,9 +786,9 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     const uint64_t fbase = (uint64_t)q * d.segq_cap;
     const uint32_t *in = d.fl[par] + slab;
     uint64_t *incs = d.inc_tab[par] + fbase;
-    const uint32_t sub = d.sub; // == gridDim.x: this workgroup owns sub-bucket blockIdx.x of every bin of the slot
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + blockIdx.x;                  // count of bin b: bkc[b * sub]
-    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap;             // sub-bucket of bin b: bk0 + b * sub * bk_cap
+    const uint32_t sub = d.sub; // == gx: this workgroup owns sub-bucket bx of every bin of the slot
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + bx;                  // count of bin b: bkc[b * sub]
+    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + bx) * d.bk_cap;             // sub-bucket of bin b: bk0 + b * sub * bk_cap
     const uint64_t bstride = (uint64_t)sub * d.bk_cap;
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
     for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += NT) {
@@ -795,10 +801,12 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
     const uint32_t ntiles = (count + NT - 1) / NT;
     const uint32_t seg_len = ntiles * GRAN;
     __shared__ uint32_t s_next;
-    for (uint32_t tile = blockIdx.x; tile < ntiles;) {
-        uint32_t next_tile = tile + gridDim.x; // narrow: static round-robin
-        if (WIDE && threadIdx.x == 0) // asked for now, needed after the tile: the atomic's latency is hidden
-            next_tile = gridDim.x + atomicAdd(&d.tile_ctr[d.launch_par][q * CSTRIDE], 1u);
+    for (uint32_t tile = bx; tile < ntiles;) {
+        uint32_t next_tile = tile + gx; // narrow: static round-robin
+        // wide: tiles are drawn from a counter (rows differ a lot in length) -- except in slot-major order, where the workgroups of a slot start
+        // far apart in time and the early ones would draw most of the tiles into THEIR sub-buckets (measured: bucket overflow, call re-run)
+        if (WIDE && !slot_major && threadIdx.x == 0) // asked for now, needed after the tile: the atomic's latency is hidden
+            next_tile = gx + atomicAdd(&d.tile_ctr[d.launch_par][q * CSTRIDE], 1u);
         // ---- one frontier entry per lane
         const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
@@ -1011,13 +1019,13 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_pushq_bin(Dev d, int 
         }
         if (WIDE && threadIdx.x == 0) s_next = next_tile;
         __syncthreads();
-        tile = WIDE ? s_next : next_tile;
+        tile = WIDE ? s_next : next_tile; // (slot-major: thread 0's next_tile is the static one)
         STAMP(5);
     }
     for (uint32_t i = threadIdx.x; i < bin_cnt; i += NT) bkc[(uint64_t)i * sub] = s_fill[i];
     if (hubmode) { // the workgroup's row of hub sums (every workgroup of the slot writes one, with or without tiles: k_accum reads them all)
         __syncthreads();
-        uint64_t *row = d.hubsum + ((uint64_t)q * sub + blockIdx.x) * d.hubs;
+        uint64_t *row = d.hubsum + ((uint64_t)q * sub + bx) * d.hubs;
         for (uint32_t i = threadIdx.x; i < d.hubs; i += NT) row[i] = s_hub[i];
     }
     STAMP_FLUSH(0);
@@ -1701,14 +1709,16 @@ __device__ __forceinline__ void accum_bin(DevRef d, int L, const int lb, const i
 constexpr int ACC_GROUP_MAX = 16;
 template <bool TO_PPR, bool WIDE>
 __global__ void __launch_bounds__(WIDE ? ACC_THREADS_WIDE : ACC_THREADS) k_accum(Dev d, int L) {
-    const int q = blockIdx.y;
-    if (!WIDE) { accum_bin<TO_PPR, WIDE>(*dev_args(), L, (int)blockIdx.x, q); return; }
+    if (!WIDE) { accum_bin<TO_PPR, WIDE>(*dev_args(), L, (int)blockIdx.x, (int)blockIdx.y); return; }
+    const bool slot_major = (d.slot_major & 2u) != 0;          // (see Dev::slot_major)
+    const int q = slot_major ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = slot_major ? blockIdx.y : blockIdx.x;
     const uint32_t G = max(d.acc_group, 1u);
     // which of my G bins have anything to do?  Their sub-bucket counts are one contiguous stretch: a coalesced trip for all of them
     constexpr int AT = WIDE ? ACC_THREADS_WIDE : ACC_THREADS;
     constexpr int BS = WIDE ? BIN_SHIFT_WIDE : BIN_SHIFT;
     __shared__ uint32_t s_gbusy[ACC_GROUP_MAX];
-    const uint32_t lb0 = blockIdx.x * G;
+    const uint32_t lb0 = bx * G;
     const uint32_t nb = min(G, (uint32_t)d.bin_cnt - lb0);
     if (G > 1) { // (uniform)
         const int par = L & 1;
@@ -1812,7 +1822,9 @@ enum { ALLOC_QUERY = 0, ALLOC_TOPK = 1, ALLOC_BOUND = 2 };
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const uint8_t *active,
                                                       uint64_t *cursor, unsigned long long *round_walks, uint32_t epoch) {
-    const int q = blockIdx.y;
+    const bool slot_major = d.wide && (d.slot_major & 8u); // (see Dev::slot_major)
+    const int q = slot_major ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = slot_major ? blockIdx.y : blockIdx.x, gx = slot_major ? gridDim.y : gridDim.x;
     const int lane = threadIdx.x & 63;
     if (MODE != ALLOC_QUERY && !active[q]) return;
     QState *qs = &d.qs[q];
@@ -1823,7 +1835,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
     if (MODE == ALLOC_QUERY) {
         if (d.opt) check_rsum *= (1 - d.alpha);       // query.h:349
         N = (uint64_t)(d.omega * check_rsum);         // query.h:270
-        if (blockIdx.x == 0 && threadIdx.x == 0) qs->n_rw = N;
+        if (bx == 0 && threadIdx.x == 0) qs->n_rw = N;
     }
     if (MODE == ALLOC_BOUND) N = (uint64_t)(d.omega * check_rsum); // query.h:645
     const bool split = MODE == ALLOC_QUERY ? d.opt != 0 : MODE == ALLOC_TOPK ? with_idx != 0 : false;
@@ -1838,7 +1850,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
     // round well under 1 % of a slab is non-zero).
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_base;
-    for (uint32_t c0 = blockIdx.x * SLAB_UNROLL; c0 < nchunk; c0 += gridDim.x * SLAB_UNROLL) {
+    for (uint32_t c0 = bx * SLAB_UNROLL; c0 < nchunk; c0 += gx * SLAB_UNROLL) {
         uint64_t rr[SLAB_UNROLL];
         bool any = false;
 #pragma unroll
@@ -2522,14 +2534,16 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     // stage: ONE word per result (destination | item << DB | extra unit << (DB + IB)) and its bin; the weight comes from the item
     __shared__ uint32_t s_msg[BINNED ? CHUNK : 1];
     __shared__ uint16_t s_bin[BINNED ? CHUNK : 1];
-    const int q = blockIdx.y;
+    const bool slot_major = NB > MAX_BINS && (d.slot_major & 4u); // (see Dev::slot_major)
+    const int q = slot_major ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = slot_major ? blockIdx.y : blockIdx.x, gx = slot_major ? gridDim.y : gridDim.x;
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (a reservation that did not fit set ERR_WIT_OVERFLOW and wrote nothing)
     if (!nitems || *d.err) return;
     const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
-    const uint32_t sub = d.sub; // BINNED: == gridDim.x, this workgroup owns sub-bucket blockIdx.x of every bin of the slot
-    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + blockIdx.x;      // count of bin b: bkc[b * sub]
-    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + blockIdx.x) * d.bk_cap; // sub-bucket of bin b: bk0 + b * sub * bk_cap
+    const uint32_t sub = d.sub; // BINNED: == gx, this workgroup owns sub-bucket bx of every bin of the slot
+    uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + bx;      // count of bin b: bkc[b * sub]
+    const uint64_t bk0 = ((uint64_t)q * d.pbins * sub + bx) * d.bk_cap; // sub-bucket of bin b: bk0 + b * sub * bk_cap
     const uint32_t bin_lo = (uint32_t)d.bin_lo, bin_cnt = (uint32_t)d.bin_cnt;
     if (BINNED) for (uint32_t i = threadIdx.x; i < (uint32_t)NB; i += NT) {
         s_cnt[i] = 0;
@@ -2538,7 +2552,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     constexpr uint32_t GRAN = FORA_TILE_GRAN_WALK; // see tile_pos
     const uint32_t ntiles = (nitems + NT - 1) / NT;
     const uint32_t seg_len = ntiles * GRAN;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t tile = bx; tile < ntiles; tile += gx) {
         const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
         if (i < nitems) {

@@ -434,14 +434,16 @@ def test_push_paths_agree_with_twin(engine, oracle, small_dangling, mode, monkey
     engine.query_fix(srcs[:1])  # back to the default plan for later tests
 
 
-@pytest.mark.parametrize("group", [1, 3, 8, 16])
-def test_wide_accumulate_bin_groups_bit_exact(engine, oracle, small_dangling, group):
+@pytest.mark.parametrize("group,slot_major", [(1, 1), (3, 0), (8, 1), (16, 0), (0, 1), (0, 0)])
+def test_wide_accumulate_bin_groups_bit_exact(engine, oracle, small_dangling, group, slot_major):
     """k_accum of the wide layouts takes `acc_group` consecutive bins of a slot per workgroup (round 6: the workgroup reads their
     counts in one trip and skips the bins with nothing to do -- overflow entries, hub sums, the dangling mass and walk results
-    included).  Same bits for any group size: push, indexed query (k_accum<true, true>) and top-k against the twin."""
+    included).  Same bits for any group size and either dispatch order (option slot_major): push, indexed query
+    (k_accum<true, true>, k_walk_idx, k_walk_alloc) and top-k against the twin."""
     g = small_dangling
     engine.set_option("force_wide", 1)
     engine.set_option("acc_group", group)
+    engine.set_option("slot_major", 15 * slot_major)  # dispatch order of the wide kernels: slot or tile / bin / chunk fastest (Dev::slot_major)
     engine.set_option("tail", 0)   # every level through the bucketed kernels
     engine.set_option("team", 0)
     try:
