@@ -39,3 +39,12 @@ def test_bench_topk_and_torchrun_rank():
               "--steps", "1", "--warmup", "1", "--scaling", "strong"])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["k"] == 50 and d["value"] > 0
     assert d["config"]["gather_bytes_per_step"] == 32 * 50 * 12
+    # the top-k line carries a roofline of its pushes on FIFO top-k push counts (oracle: orc_topk_push_counts with the GPU run's rounds)
+    r = d["roofline"]
+    assert r is not None and r["bound"] == "hbm" and 0 < r["frac"] < 1 and "FIFO top-k pushes" in r["algorithmic_counts"]
+
+
+def test_bench_line_names_the_walk_bound_and_its_sources():
+    d = _run([sys.executable, "bench.py", "--graph", "small", "--queries", "64", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-accuracy", "--no-variants"])
+    w = d["walk_bound"]  # the dominant kernel of the headline step: gathers per second, not an HBM fraction
+    assert w["gathers_per_s"] > 0 and w["steps"] > 0 and "k_walk_dg" in w["kernel"]

@@ -361,3 +361,23 @@ def test_query_many_matches_single_queries(oracle, tiny):
         assert done == len(srcs) and w == walks and dt > 0
     done, _, _ = oracle.query_many(g, srcs, rmax, omega, 2, 0.0, seed=3)  # budget spent at once: one query per thread
     assert done == 2
+
+
+def test_topk_push_counts_follow_the_rounds(oracle, small):
+    """orc_topk_push_counts (bench.py's roofline of the top-k configuration): the pushes of the first r rounds of the --opt
+    driver without the walks between them.  The push state does not depend on the walks, so the counts of r rounds are those
+    of r - 1 rounds plus one more push; a dangling source pushes nothing; the full run's round count is a valid argument."""
+    g = small
+    s = int(np.flatnonzero(g.deg > 0)[11])
+    _, _, rounds, _ = oracle.topk_query(g, s, 50, 0.5, seed=7)
+    assert rounds >= 1
+    prev = (0, 0)
+    for r in range(1, rounds + 2):
+        cur = oracle.topk_push_counts(g, s, 50, 0.5, r)
+        assert cur[0] >= prev[0] and cur[1] >= prev[1]
+        prev = cur
+    assert prev[0] > 0 and prev[1] > 0
+    one = oracle.topk_push_counts(g, s, 50, 0.5, 1)
+    fifo = oracle.push_fifo(g, s, oracle.fora_topk_setting(g.m, 0.5, 1.0 / 50 / 10, 1.0 / g.n / g.n)[0]) if hasattr(oracle, "fora_topk_setting") else None
+    if fifo is not None:  # round 1 is a plain FIFO push from the source at the round's rmax: same pops and relaxations
+        assert one == (fifo["pops"], fifo["relax"])
