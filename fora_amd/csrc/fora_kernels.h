@@ -253,10 +253,10 @@ struct Dev {
     uint32_t hubs, hub_min;
     uint32_t tail_hubs;     // != 0: k_push_tail sums the increments for hubs in LDS too (its launches pass hubs * 8 bytes of dynamic LDS)
     uint32_t tiny_max; // k_accum: buckets of up to this many messages go by direct atomics instead of the LDS sweep
-    uint32_t slot_major; // wide layouts, one bit per kernel (1: k_pushq_bin, 2: k_accum, 4: k_walk_idx, 8: k_walk_alloc): the launch puts the SLOT in blockIdx.x (the fastest-varying
-                         // index of the dispatch order) and the tile / bin / chunk in blockIdx.y: the workgroups in flight at one time then work on the same
-                         // stretch of the graph for many slots, and what they share -- rows of col, degrees, index segments -- is fetched from HBM once and
-                         // hit in L2 by the others (round 6, profiles/r06_slot_major.txt)
+    uint32_t slot_major; // wide layouts, one bit per kernel (1: k_pushq_bin, 2: k_accum, 4: k_walk_idx, 8: k_walk_alloc): the launch puts the SLOT in blockIdx.x
+                         // (the fastest-varying index of the dispatch order) and the tile / bin / chunk in blockIdx.y, so that the workgroups in flight at one time
+                         // belong to many slots instead of a few.  Measured, not derived (round 6, profiles/r06_slot_major.txt): LJ-sized launches of 143 slots gain
+                         // 4-9 % in the bin kernel and ~5 % in the indexed walks; HBM read bytes and L2 hit counts are the same in both orders
     uint32_t acc_group; // k_accum (wide layouts): consecutive bins of a slot per workgroup (>= 1).  The workgroup reads their counts in one coalesced trip and
                         // skips the bins that have nothing to do: 94 k one-bin workgroups per launch cost 0.74 ms when nearly all of them are empty (sparse levels,
                         // top-k rounds)
