@@ -715,7 +715,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     // Dispatch order of the wide kernels (Dev::slot_major), measured per kernel (profiles/r06_slot_major.txt): slot-major pays for the bin kernel
     // when a launch holds many slots (LJ-sized, 143 slots: 1135-1205 -> 1073-1107 ms per 1000 queries in A/B runs; Twitter-2010-sized, 8 slots:
     // 620 -> 930 ms) and for the indexed walks of query calls (LJ-sized ~ - 5 %, Twitter-2010-sized - 2 %); it loses for the accumulate, the walk
-    // allocation and everything in the top-k drivers.  Not cache reuse: FETCH_SIZE and TCC hits / misses are the same in both orders.
+    // allocation and everything in the top-k drivers.  FETCH_SIZE and TCC hits / misses are the same in both orders: if it is reuse, it is in the memory-side Infinity Cache.
     d.slot_major = c->opt_.slot_major >= 0 ? (uint32_t)c->opt_.slot_major & 15u
                    : (c->bk_div > 1 ? 0u : (4u | (nq >= 32 ? 1u : 0u)));
     d.tiny_max = (uint32_t)std::min<int64_t>(std::max<int64_t>(c->opt_.tiny, 0), 1023); // 512: ws accum 116 -> 113 ms per 3000 queries against 128; 2048: 119, 8192: 193 (the crossing list of the small-bucket path holds 1024)

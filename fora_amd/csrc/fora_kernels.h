@@ -256,7 +256,8 @@ struct Dev {
     uint32_t slot_major; // wide layouts, one bit per kernel (1: k_pushq_bin, 2: k_accum, 4: k_walk_idx, 8: k_walk_alloc): the launch puts the SLOT in blockIdx.x
                          // (the fastest-varying index of the dispatch order) and the tile / bin / chunk in blockIdx.y, so that the workgroups in flight at one time
                          // belong to many slots instead of a few.  Measured, not derived (round 6, profiles/r06_slot_major.txt): LJ-sized launches of 143 slots gain
-                         // 4-9 % in the bin kernel and ~5 % in the indexed walks; HBM read bytes and L2 hit counts are the same in both orders
+                         // 4-9 % in the bin kernel and ~5 % in the indexed walks; HBM-side bytes and L2 hit counts are the same in both orders, the
+                         // requests are served faster (Infinity Cache reuse is the hypothesis that fits)
     uint32_t acc_group; // k_accum (wide layouts): consecutive bins of a slot per workgroup (>= 1).  The workgroup reads their counts in one coalesced trip and
                         // skips the bins that have nothing to do: 94 k one-bin workgroups per launch cost 0.74 ms when nearly all of them are empty (sparse levels,
                         // top-k rounds)
