@@ -1092,8 +1092,10 @@ int reset_binned_counters(fora_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_bk_count, 0, (size_t)c->B * c->pbins * c->sub * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_count, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ov_bin, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_dbm, 0, 2 * (size_t)c->B * c->dbm_words * 8, c->stream)); // (a complete push leaves them clear; an aborted one may not)
-    HIPCHK(c, hipMemsetAsync(c->d_dflag, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
+    if (TEST_PATHS) { // bounded deferral's bitmaps and flags (test library only; 385 MB per top-k round at Twitter-2010 size)
+        HIPCHK(c, hipMemsetAsync(c->d_dbm, 0, 2 * (size_t)c->B * c->dbm_words * 8, c->stream)); // (a complete push leaves them clear; an aborted one may not)
+        HIPCHK(c, hipMemsetAsync(c->d_dflag, 0, 2 * (size_t)c->B * c->nbins * 4, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_tile_ctr, 0, 2 * (size_t)c->B * 4 * CSTRIDE, c->stream)); // both parity sets, every slot: a launch only re-zeroes the slots it runs
     return FORA_OK;
 }
@@ -2168,7 +2170,7 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
         c->topk_cap = c->B * k;
     }
     const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
-    std::vector<uint8_t> active;
+    std::vector<uint8_t> active, inactive;
     std::vector<unsigned long long> above;
     const int per = even_batch(nq, c->B);
     for (int b0 = 0; b0 < nq; b0 += per) {
@@ -2184,9 +2186,15 @@ static int topk_batch_impl(fora_ctx *c, const int32_t *sources, int nq, int k, d
             if (c->h_row_ptr[sources[b0 + i] + 1] == c->h_row_ptr[sources[b0 + i]]) active[i] = 0;
         std::vector<int32_t> nround((size_t)nb, 1);
         std::vector<double> sel_thr((size_t)nb, 0.0); // slots that stop with k entries >= T: the top k are among those
-        // ppr2 := reserve for every slot once (covers dangling sources)
-        hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
-                           (const uint8_t *)nullptr);
+        // ppr2 := reserve once for the slots that never run a round (dangling sources: ppr = e_s); every other slot's ppr2 is written
+        // by its first round's copy (round 5 copied all slots here: one 12-GB slab pass per Twitter-2010-sized batch for nothing)
+        inactive.assign((size_t)nb, 0);
+        bool any_inactive = false;
+        for (int i = 0; i < nb; i++) { inactive[i] = active[i] ? 0 : 1; any_inactive |= inactive[i] != 0; }
+        if (any_inactive) {
+            HIPCHK(c, hipMemcpyAsync(c->d_active, inactive.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2, (const uint8_t *)c->d_active);
+        }
         double delta = init_delta;
         int round = 0;
         while (delta >= min_delta) { // query.h:1001
@@ -2330,7 +2338,7 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
         c->lb_cap = c->B * k;
     }
     const uint32_t chunks = slab_grid_x(c, std::min(nq, c->B));
-    std::vector<uint8_t> active;
+    std::vector<uint8_t> active, inactive;
     std::vector<unsigned long long> above;
     std::vector<uint32_t> failv;
     const int per = even_batch(nq, c->B);
@@ -2347,8 +2355,13 @@ static int topk_bound_batch_impl(fora_ctx *c, const int32_t *sources, int nq, in
         for (int i = 0; i < nb; i++) // dangling source: query.h:951-955
             if (c->h_row_ptr[sources[b0 + i] + 1] == c->h_row_ptr[sources[b0 + i]]) active[i] = 0;
         std::vector<int32_t> nround((size_t)nb, 1);
-        hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2,
-                           (const uint8_t *)nullptr);
+        inactive.assign((size_t)nb, 0); // (see fora_hip_topk_batch: only the slots that never run a round need this copy)
+        bool any_inactive = false;
+        for (int i = 0; i < nb; i++) { inactive[i] = active[i] ? 0 : 1; any_inactive |= inactive[i] != 0; }
+        if (any_inactive) {
+            HIPCHK(c, hipMemcpyAsync(c->d_active, inactive.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_copy_slab, dim3(chunks, nb), dim3(BLOCK), 0, c->stream, c->n, c->d_ppr, c->d_ppr2, (const uint8_t *)c->d_active);
+        }
         double delta = init_delta;
         int round = 0;
         while (delta >= min_delta) { // query.h:944
