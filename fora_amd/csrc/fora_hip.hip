@@ -398,11 +398,11 @@ static WsPlan plan_workspace(const fora_ctx *c, double omega_hint, int slots) {
             p.bk_cap = (uint32_t)((cap + 15) & ~15ull);
         }
         p.segq_cap = n; // frontier positions
-        p.scratch = p.wits * sizeof(WalkItem);
+        p.scratch = (p.wits * sizeof(WalkItemP) + 95) / 96 * 96; // whole PushSeg (24 B) and WalkItemP (32 B) entries: `keepable` compares seg_cap * sizeof(PushSeg) with it
         p.per_slot = n * 8 * 2 + n * 4 * 2 + p.segq_cap * 8 * 2 + std::max<uint64_t>(262144, n / 8) * 12 + (uint64_t)p.pbins * p.sub * p.bk_cap * (want_wide(c) ? 8 : 12) + p.scratch +
                      (c->opt_.defer > 0 ? n * 4 * 2 : 0) + n / 4 + 64 + (uint64_t)p.sub * c->hubs * 8; // + deferred lists and bitmaps, hub sums
     } else {
-        p.scratch = std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItem));
+        p.scratch = (std::max(p.segs * sizeof(PushSeg), p.wits * sizeof(WalkItemP)) + 95) / 96 * 96;
         p.per_slot = n * 8 * 4 + p.scratch;
     }
     return p;
@@ -693,7 +693,7 @@ Dev make_dev(fora_ctx *c, int nq, bool with_idx, double rmax = -1, double omega 
     d.residue = c->d_residue; d.ppr = c->d_ppr;
     d.wl[0] = c->d_wl[0]; d.wl[1] = c->d_wl[1]; d.wl_cap = c->wl_cap;
     d.seg = (PushSeg *)c->d_scratch; d.seg_cap = c->seg_cap;
-    d.wit = (WalkItem *)c->d_scratch; d.wit_cap = c->wit_cap;
+    d.wit = (WalkItemP *)c->d_scratch; d.wit_cap = c->wit_cap;
     d.wl_count = c->d_counters;
     d.seg_count = c->d_counters + (MAX_LEVELS + 2);
     d.wit_count = c->d_wit_count;

@@ -135,16 +135,47 @@ struct PushSeg {      // one <=PUSH_SEG-edge slice of a popped node's out-edges
     uint32_t cnt;     // edges in this slice
 };
 
-struct WalkItem {     // <=WALK_SEG walks that start at one residue node
-    uint64_t j0;      // walk number of the first walk (Philox counter word)
+struct WalkItem {     // <=WALK_SEG walks that start at one residue node: what the walk kernels work with
+    uint64_t j0;      // walk number of the first walk (Philox counter word): a multiple of WALK_SEG
     uint64_t idx_pos; // MODE ppr: rw_idx position of walk j0; MODE index: output position
     uint64_t incr;    // weight per walk: r / num_s_rw (query.h:283-285)
     uint64_t rem;     // walks j < rem carry one extra 2^-62 unit (keeps the sum exact)
-    uint32_t q;
     uint32_t v;       // start node
-    uint32_t cnt;     // walks in this item
+    uint32_t cnt;     // walks in this item (1 .. WALK_SEG)
     uint32_t idx_n;   // leading walks of the item served from the index (query.h:290-307)
 };
+// ... and how an item lies in memory: 32 bytes (48 until round 6).  With the index nearly every node of an LJ- or Twitter-2010-sized
+// slot is an item: 33 GB of items per LJ-sized batch, written by k_walk_alloc and read by k_walk_idx -- a sixth of the latter's traffic.
+struct WalkItemP {
+    uint64_t w0;      // v (32) | cnt - 1 (10) << 32 | idx_n (11) << 42
+    uint64_t w1;      // j0 / WALK_SEG (28) | rem (36) << 28
+    uint64_t idx_pos;
+    uint64_t incr;
+};
+static_assert(sizeof(WalkItemP) == 32, "two 16-byte words");
+__device__ __forceinline__ WalkItemP wit_pack(const WalkItem &w) {
+    WalkItemP p;
+    p.w0 = (uint64_t)w.v | ((uint64_t)(w.cnt - 1u) << 32) | ((uint64_t)w.idx_n << 42);
+    p.w1 = (w.j0 / WALK_SEG) | (w.rem << 28); // (rem < the node's walk count < 2^36, j0 < 2^38: checked by k_walk_alloc -> ERR_WIT_OVERFLOW)
+    p.idx_pos = w.idx_pos;
+    p.incr = w.incr;
+    return p;
+}
+__device__ __forceinline__ WalkItem wit_unpack(uint64_t w0, uint64_t w1, uint64_t idx_pos, uint64_t incr) {
+    WalkItem w;
+    w.v = (uint32_t)w0;
+    w.cnt = ((uint32_t)(w0 >> 32) & 1023u) + 1u;
+    w.idx_n = (uint32_t)(w0 >> 42) & 2047u;
+    w.j0 = (w1 & ((1ull << 28) - 1)) * WALK_SEG;
+    w.rem = w1 >> 28;
+    w.idx_pos = idx_pos;
+    w.incr = incr;
+    return w;
+}
+__device__ __forceinline__ WalkItem wit_load(const WalkItemP *p) {
+    const uint4 a = ((const uint4 *)p)[0], b = ((const uint4 *)p)[1];
+    return wit_unpack(((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, ((uint64_t)b.y << 32) | b.x, ((uint64_t)b.w << 32) | b.z);
+}
 
 struct QState {       // per-slot accumulators
     unsigned long long reserved; // sum of reserve so far; rsum_fix = FIX_ONE - reserved (algo.h:992)
@@ -205,7 +236,7 @@ struct Dev {
     uint64_t wl_cap;
     PushSeg *seg;
     uint64_t seg_cap;
-    WalkItem *wit;          // [slot][wit_cap] walk items of a slot
+    WalkItemP *wit;         // [slot][wit_cap] walk items of a slot
     uint64_t wit_cap;       // per slot
     uint32_t *wit_count;    // [slot * CSTRIDE]
     unsigned long long *wl_count;  // [MAX_LEVELS + 2] frontier size per level
@@ -1876,6 +1907,7 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                 }
                 if (MODE == ALLOC_QUERY || (MODE == ALLOC_BOUND && !with_idx)) num[u] = walk_count(fix2d(r), check_rsum, N); // :727
                 else num[u] = (uint64_t)ceil(fix2d(r) * d.omega); // query.h:568 / :618 / :659
+                if (num[u] >> 36) { atomicOr(d.err, ERR_WIT_OVERFLOW); num[u] = 0; } // (a packed item holds walk counts below 2^36: far beyond any item list)
                 if (num[u]) {
                     incr[u] = r / num[u];
                     rem[u] = r - incr[u] * num[u];
@@ -1926,9 +1958,8 @@ __global__ void __launch_bounds__(BLOCK) k_walk_alloc(Dev d, int with_idx, const
                 w.idx_n = a < w.cnt ? (uint32_t)a : w.cnt;
                 w.incr = incr[u];
                 w.rem = rem[u];
-                w.q = (uint32_t)q;
                 w.v = c0 * BLOCK + threadIdx.x * SLAB_UNROLL + u;
-                d.wit[(uint64_t)q * d.wit_cap + at++] = w;
+                d.wit[(uint64_t)q * d.wit_cap + at++] = wit_pack(w);
             }
         }
     }
@@ -2371,7 +2402,7 @@ __global__ void __launch_bounds__(BLOCK) k_index_alloc(Dev d) {
                     w.cnt = left < WALK_SEG ? (uint32_t)left : WALK_SEG;
                     w.idx_pos = ioff + w.j0;
                     w.v = v;
-                    d.wit[sb + off + k] = w; // slot 0
+                    d.wit[sb + off + k] = wit_pack(w); // slot 0
                 }
             }
         }
@@ -2540,7 +2571,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
     const uint32_t bx = slot_major ? blockIdx.y : blockIdx.x, gx = slot_major ? gridDim.y : gridDim.x;
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (a reservation that did not fit set ERR_WIT_OVERFLOW and wrote nothing)
     if (!nitems || *d.err) return;
-    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const WalkItemP *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t sub = d.sub; // BINNED: == gx, this workgroup owns sub-bucket bx of every bin of the slot
     uint32_t *bkc = d.bk_count + (uint64_t)q * d.pbins * sub + bx;      // count of bin b: bkc[b * sub]
@@ -2557,7 +2588,7 @@ __global__ void __launch_bounds__(BinThreads<NB>::value) k_walk_idx(Dev d) {
         const uint32_t i = tile_pos<GRAN>(threadIdx.x, tile, seg_len);
         uint32_t cnt = 0;
         if (i < nitems) {
-            const WalkItem w = items[i];
+            const WalkItem w = wit_load(&items[i]);
             s_j0[threadIdx.x] = w.j0; s_pos[threadIdx.x] = w.idx_pos;
             s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
             cnt = w.idx_n;
@@ -2687,7 +2718,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
     const int q = blockIdx.y;
     const uint32_t nitems = (uint32_t)min((uint64_t)d.wit_count[q * CSTRIDE], d.wit_cap); // (see k_walk_idx)
     if (!nitems || *d.err) return;
-    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const WalkItemP *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t stream = MODE == WALK_TO_INDEX ? 0xFFFFFFFFu : (uint32_t)d.src[q];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -2703,7 +2734,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FORA
         const uint32_t i = tbase + threadIdx.x;
         uint32_t cnt = 0;
         if (i < nitems) {
-            const WalkItem w = items[i];
+            const WalkItem w = wit_load(&items[i]);
             s_j0[threadIdx.x] = w.j0; s_pos[threadIdx.x] = w.idx_pos;
             s_incr[threadIdx.x] = w.incr; s_rem[threadIdx.x] = w.rem;
             s_v[threadIdx.x] = w.v;
@@ -2875,7 +2906,7 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
     for (uint32_t i = threadIdx.x; i < g.nrec; i += DG_THREADS) s_rec[i] = make_uint4(g.rec[i], g.rec[g.nrec + i], g.rec[2 * g.nrec + i], 0u);
     for (uint32_t i = threadIdx.x; i < (g.nblk + 3) / 4; i += DG_THREADS) dg_lds[4 * g.nrec + i] = ((const uint32_t *)g.T)[i];
     if (XL) for (uint32_t i = threadIdx.x; i < H; i += DG_THREADS) s_hub[i] = 0;
-    const WalkItem *items = d.wit + (uint64_t)q * d.wit_cap;
+    const WalkItemP *items = d.wit + (uint64_t)q * d.wit_cap;
     const uint64_t slab = (uint64_t)q * d.n;
     const uint32_t stream = (uint32_t)d.src[q];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -2938,11 +2969,11 @@ __global__ void __launch_bounds__(DG_THREADS) __attribute__((amdgpu_waves_per_eu
                     WalkItem w; // read once: keep the items out of the way of the packed targets in L2
                     {
                         const uint64_t *wp = (const uint64_t *)&items[i];
-                        uint64_t x0 = NT_LOAD(wp), x2 = NT_LOAD(wp + 2), x3 = NT_LOAD(wp + 3), x4 = NT_LOAD(wp + 4), x5 = NT_LOAD(wp + 5);
-                        w.j0 = x0; w.idx_pos = 0; w.incr = x2; w.rem = x3; w.q = (uint32_t)x4; w.v = (uint32_t)(x4 >> 32); w.cnt = (uint32_t)x5; w.idx_n = (uint32_t)(x5 >> 32);
+                        const uint64_t x0 = NT_LOAD(wp), x1 = NT_LOAD(wp + 1), x3 = NT_LOAD(wp + 3); // (online walks: no index position)
+                        w = wit_unpack(x0, x1, 0, x3);
                     }
 #else
-                    const WalkItem w = items[i];
+                    const WalkItem w = wit_load(&items[i]);
 #endif
                     s_j0[lane] = w.j0; s_incr[lane] = w.incr; s_rem[lane] = w.rem;
                     s_v[lane] = w.v;
